@@ -1,0 +1,192 @@
+"""The CPU oracle must reproduce the vectors generated from the reference (tests/golden)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, relerr
+from oracle import onmf_oracle as orc
+
+TOL = 1e-11          # fp64 restatement vs fp64 reference: BLAS summation order only
+
+
+def test_g1_code_sweeps_all_variants():
+    g = load_golden("g1_code")
+    for alpha in (0, 1):
+        for key, tol in (("01", 0.01), ("0", 0.0)):
+            tr = []
+            H = orc.code_sweeps(g["X"], g["W"], H0=g["H0"].copy(), alpha=alpha, sub_iter=10,
+                                stopping_diff=tol, trace=tr)
+            name = "a%d_t%s" % (alpha, key)
+            assert relerr(H, g["H_" + name]) < TOL
+            d = np.array([x[1] for x in tr])
+            assert len(d) == len(g["dist_" + name])
+            np.testing.assert_allclose(d, g["dist_" + name], rtol=1e-9)
+
+
+def test_g1_early_stop_and_single_column():
+    g = load_golden("g1_code")
+    tr = []
+    H = orc.code_sweeps(g["X"], g["W"], H0=g["H0_early"].copy(), alpha=0, sub_iter=10,
+                        stopping_diff=0.01, trace=tr)
+    assert len(tr) == len(g["dist_early"]) < 10          # the reference stopped early here
+    assert relerr(H, g["H_early"]) < TOL
+    tr = []
+    Hs = orc.code_sweeps(g["X"][:, :1], g["W"], H0=g["H0"][:, :1].copy(), alpha=1, sub_iter=10,
+                         stopping_diff=0.01, trace=tr)
+    assert len(tr) == len(g["dist_single"])
+    assert relerr(Hs, g["H_single"]) < TOL
+
+
+def test_g1_gram_norm_equals_svd_norm():
+    g = load_golden("g1_code")
+    tr = []
+    orc.code_sweeps(g["X"], g["W"], H0=g["H0"].copy(), alpha=0, sub_iter=10, stopping_diff=0.01,
+                    norm="gram", trace=tr)
+    np.testing.assert_allclose([x[1] for x in tr], g["dist_a0_t01"], rtol=1e-7)
+
+
+def test_g1_radius_branch():
+    g = load_golden("g1_code")
+    H = orc.code_sweeps(g["X"][:, :6], g["W"], H0=g["H0"][:, :6].copy(), r=0.5, alpha=0,
+                        sub_iter=3, stopping_diff=0.0)
+    assert relerr(H, g["H_radius"]) < TOL
+
+
+def test_g2_dictionary_pass():
+    g = load_golden("g2_dict")
+    assert relerr(orc.dictionary_pass(g["W"], g["A"], g["B"]), g["W1"]) < TOL
+    assert np.all(g["W1"][:, 3] == 0)                    # the clipped-to-zero atom is in the data
+    r, d = g["B"].shape
+    Wz = orc.dictionary_pass(g["W"], np.zeros((r, r)), np.zeros((r, d)))
+    assert relerr(Wz, g["W1_zero_agg"]) < TOL
+
+
+def test_g3_steps_chain():
+    g = load_golden("g3_steps")
+    r, d = g["W0"].shape[1], g["W0"].shape[0]
+    W = g["W0"]
+    agg = [np.zeros((r, r)), np.zeros((r, d))]
+    for s in range(3):
+        tr = []
+        H, agg, W, hist = orc.minibatch_step(g["X"], agg, W, s + 1, H0=g["H0_%d" % s], trace=tr)
+        assert relerr(H, g["H_%d" % s]) < TOL
+        assert relerr(agg[0], g["A_%d" % s]) < TOL
+        assert relerr(agg[1], g["B_%d" % s]) < TOL
+        assert relerr(W, g["W_%d" % s]) < TOL
+        assert hist == g["hist_%d" % s]
+        assert len(tr) == len(g["dist_%d" % s])
+    # the first step sees zero aggregates: the dictionary is only clipped and normalised
+    W1 = g["W_0"]
+    np.testing.assert_allclose(W1, g["W0"] / np.maximum(1, np.linalg.norm(g["W0"], axis=0)),
+                               rtol=1e-12)
+
+
+def _run_train(g, seed, cls_kwargs, full_code=False, draw_x=None):
+    np.random.seed(seed)
+    X = np.random.rand(*g["X"].shape)
+    np.testing.assert_array_equal(X, g["X"])
+    nmf = orc.OracleOnlineNMF(X, **cls_kwargs)
+    return nmf, nmf.train_dict(full_code=full_code)
+
+
+def test_g4_train_then_warm_restart_global_rng_order():
+    g = load_golden("g4_train_warm")
+    r = g["W0"].shape[1]
+    n = g["X"].shape[1]
+    nmf, (W, agg, code) = _run_train(g, 14, dict(n_components=r, iterations=5, batch_size=n))
+    assert relerr(W, g["W"]) < TOL and relerr(agg[0], g["A"]) < TOL and relerr(agg[1], g["B"]) < TOL
+    assert relerr(code, g["code"]) < TOL
+    assert nmf.history == g["hist"] == 5.0
+    nmf2 = orc.OracleOnlineNMF(g["X"], n_components=r, iterations=5, batch_size=n, ini_dict=W,
+                               ini_agg=agg, history=nmf.history)
+    W2, agg2, code2 = nmf2.train_dict()
+    assert relerr(W2, g["W_b"]) < TOL and relerr(agg2[0], g["A_b"]) < TOL
+    assert relerr(agg2[1], g["B_b"]) < TOL and relerr(code2, g["code_b"]) < TOL
+    assert nmf2.history == g["hist_b"] == 10.0           # t skipped the value 5
+
+
+def test_g5_subsample_duplicates():
+    g = load_golden("g5_subsample")
+    r = g["W0"].shape[1]
+    nmf, (W, agg, code) = _run_train(g, 15, dict(n_components=r, iterations=4, batch_size=32,
+                                                 subsample=True))
+    assert relerr(W, g["W"]) < TOL and relerr(agg[0], g["A"]) < TOL
+    assert relerr(code, g["code"]) < TOL
+    assert nmf.history == g["hist"]
+
+
+def test_g6_full_code_and_surrogate_loss():
+    g = load_golden("g6_full_code")
+    r = g["W0"].shape[1]
+    n = g["X"].shape[1]
+    nmf, (W, agg, code) = _run_train(g, 16, dict(n_components=r, iterations=4, batch_size=n),
+                                     full_code=True)
+    assert len(agg) == 3
+    for got, key in zip([W, *agg], ["W", "A", "B", "C"]):
+        assert relerr(got, g[key]) < TOL
+    assert abs(orc.surrogate_loss(W, *agg) - g["loss"]) < 1e-9 * max(1.0, abs(g["loss"]))
+
+
+def test_g7_beta_alpha_with_restart():
+    g = load_golden("g7_beta_alpha")
+    r = g["W0"].shape[1]
+    n = g["X"].shape[1]
+    kw = dict(n_components=r, iterations=3, batch_size=n, alpha=0.3, beta=0.5)
+    nmf, (W, agg, _) = _run_train(g, 17, kw)
+    assert relerr(W, g["W"]) < TOL and relerr(agg[1], g["B"]) < TOL
+    nmf2 = orc.OracleOnlineNMF(g["X"], ini_dict=W, ini_agg=agg, history=nmf.history, **kw)
+    W2, agg2, _ = nmf2.train_dict()
+    assert relerr(W2, g["W_b"]) < TOL and relerr(agg2[0], g["A_b"]) < TOL
+    assert nmf2.history == g["hist_b"]
+
+
+def test_g8_stream_with_injected_draws():
+    g = load_golden("g8_stream")
+    r = g["W0"].shape[1]
+    W, agg, hist = None, None, 0
+    sweeps = []
+    for it in range(g["Xs"].shape[0]):
+        X = g["Xs"][it]
+        if W is None:
+            W = g["W0"]
+            agg = [np.zeros((r, r)), np.zeros((r, X.shape[0]))]
+        tr = []
+        # iterations=2 -> one step at t = hist + 1 with the call's initial aggregates
+        _, agg, W, hist = orc.minibatch_step(X, agg, W, hist + 1, H0=g["H0s"][it], trace=tr)
+        sweeps.append(len(tr))
+    assert sweeps == list(g["sweeps"])
+    assert relerr(W, g["W"]) < 1e-10 and relerr(agg[0], g["A"]) < 1e-10
+    assert relerr(agg[1], g["B"]) < 1e-10
+    assert hist == g["hist"]
+    H = orc.code_sweeps(g["Xs"][-1], W, H0=g["H_last0"], alpha=0, sub_iter=10, stopping_diff=0.01)
+    assert relerr(H, g["H_last"]) < 1e-10
+    resid = np.linalg.norm(g["Xs"][-1] - W @ H) / np.linalg.norm(g["Xs"][-1])
+    assert abs(resid - g["resid"]) < 1e-10
+
+
+@pytest.mark.parametrize("name,alpha", [("default2", None), ("a05", 0.5), ("a005", 0.05)])
+def test_g9_lasso_matches_sklearn_vectors(name, alpha):
+    g = load_golden("g9_lasso")
+    want = g["H_" + name]
+    got = orc.lasso_nonneg_code(g["X"], g["W"], alpha, solver="sklearn")
+    np.testing.assert_allclose(got, want, atol=1e-12)
+    cd = orc.lasso_nonneg_code(g["X"], g["W"], alpha, solver="cd")
+    a = 2 if alpha is None else alpha
+    # Same convex problem.  scikit-learn's positive LARS path stops slightly short of the optimum
+    # (objective up to 0.4 % above the coordinate-descent fixed point at small alpha), so the
+    # comparison is: CD objective never worse, same support, codes within 5e-2 absolute.
+    f_cd = orc.lasso_objective(g["X"], g["W"], cd.T, a)
+    f_sk = orc.lasso_objective(g["X"], g["W"], want.T, a)
+    assert np.all(f_cd <= f_sk * (1 + 1e-9) + 1e-12)
+    assert np.all(f_sk <= f_cd * (1 + 5e-3))
+    assert np.array_equal(cd > 0, want > 0)
+    np.testing.assert_allclose(cd, want, atol=5e-2)
+
+
+def test_unfold3_shapes_and_layout():
+    T = np.arange(4 * 3 * 5, dtype=np.float64).reshape(4, 3, 5)
+    assert orc.unfold3(T, 0).shape == (4, 15)
+    assert orc.unfold3(T, 1).shape == (3, 20)
+    assert orc.unfold3(T, 2).shape == (5, 12)
+    np.testing.assert_array_equal(orc.unfold3(T, 0), T.reshape(4, 15))
+    np.testing.assert_array_equal(orc.unfold3(T, 2)[1], T[:, :, 1].reshape(-1))
+    np.testing.assert_array_equal(orc.unfold3(T, 1)[2], T[:, 2, :].reshape(-1))
