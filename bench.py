@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""Throughput of the ONMF minibatch step (sparse code + aggregates + dictionary pass) on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path over one resident synthetic batch (X ~ U[0,1), d x b).
+At N > 1 every rank runs its own patch stream (weak scaling) and the ranks average the packed
+state [A|B|W] over RCCL every --sync-every steps, inside the timed region.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (d, r, b)
+    "headline": (1024, 256, 65536),      # the shape the 50 %-of-roofline target is quoted on
+    "c2": (1024, 64, 8192),              # BASELINE.json configs[1]
+    "c4": (4096, 256, 65536),            # configs[3], per GPU
+    "c3": (1200, 100, 8192),
+    "c1": (100, 16, 1000),
+    "c5": (441, 25, 1000),
+}
+PEAK_FP32_MFMA_TFLOPS = 157.3
+SWEEPS = 10
+
+
+def step_flops(d, r, b, sweeps):
+    """W^T X + H X^T + sweeps + H H^T + W^T W + dictionary pass (flops, fused multiply-add = 2)."""
+    return 4.0 * d * r * b + 2.0 * r * r * b * (sweeps + 1) + 4.0 * d * r * r
+
+
+def cpu_baseline(d, r, budget_cols):
+    """Time the NumPy oracle (float64, spectral-norm test by SVD like the reference) on a bounded
+    sample of the same workload: same d and r, fewer columns."""
+    from oracle import onmf_oracle as orc
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    rs = np.random.RandomState(1234)
+    b = budget_cols
+    X = rs.rand(d, b)
+    W = rs.rand(d, r)
+    W /= np.maximum(1, np.linalg.norm(W, axis=0))
+    A, B = np.zeros((r, r)), np.zeros((r, d))
+    # one untimed warm step so (A,B) are non-zero, then timed steps
+    _, (A, B), W, _ = orc.minibatch_step(X, [A, B], W, 1, H0=rs.rand(r, b))
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        tr = []
+        _, (A, B), W, _ = orc.minibatch_step(X, [A, B], W, n + 2, H0=rs.rand(r, b), trace=tr)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > 10.0 or n >= 5:
+            break
+    return {"value": b * n / el, "unit": "patches/s", "cores": int(threads), "kind": "port",
+            "sample": "oracle/onmf_oracle.py minibatch_step, float64, SVD stopping test, d=%d r=%d, "
+                      "%d steps of %d columns (%d sweeps in the last), %.1f s" % (d, r, n, b, len(tr), el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="headline", choices=sorted(WORKLOADS))
+    ap.add_argument("--stopping-diff", type=float, default=0.01,
+                    help="0.01 = the reference's sparse_code setting; 0 = always 10 sweeps")
+    ap.add_argument("--sync-every", type=int, default=4, help="steps between (A,B,W) all-reduces at N>1")
+    ap.add_argument("--batches", type=int, default=3, help="distinct resident batches cycled through")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-cols", type=int, default=0, help="columns of the CPU-baseline sample (0 = auto)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as td
+    from onmf_ontf_ndl_amd import dist as odist
+    from onmf_ontf_ndl_amd import _lib
+    from onmf_ontf_ndl_amd.engine import get_engine
+
+    rank, world, local = odist.init_from_env()
+    if world != args.gpus:
+        if rank == 0:
+            sys.stderr.write("bench: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE\n" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU path)")
+    torch.cuda.set_device(local)
+    eng = get_engine(torch.device("cuda", local))
+    d, r, b = WORKLOADS[args.workload]
+
+    gen = torch.Generator(device=eng.device).manual_seed(1234 + rank)
+    Xs = [torch.rand(d, b, device=eng.device, generator=gen) for _ in range(max(1, args.batches))]
+    gw = torch.Generator(device=eng.device).manual_seed(4321)
+    W = torch.rand(d, r, device=eng.device, generator=gw)
+    A, B = eng.zeros(r, r), eng.zeros(r, d)
+    W = eng.update_dict(W, A, B)                 # clip + normalise, as the reference's first step does
+    t = 1
+    sweeps_seen = []
+
+    def one_step(i):
+        nonlocal W, A, B, t
+        _, A, B, _, W, s, _ = eng.step(Xs[i % len(Xs)], A, B, None, W, 1.0 / t, alpha=0.0, H0=None,
+                                       seed=1000 * rank + t, sub_iter=SWEEPS,
+                                       stopping_diff=args.stopping_diff, want_code=False)
+        t += 1
+        if world > 1 and args.sync_every > 0 and (t % args.sync_every) == 0:
+            W, A, B = odist.average_state(W, A, B)
+        return s
+
+    for i in range(max(args.warmup, 0)):
+        one_step(i)
+    eng.set_option(_lib.OPT_PROFILE, 1)
+    eng.get_profile()
+    if world > 1:
+        td.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        sweeps_seen.append(one_step(args.warmup + i))
+    torch.cuda.synchronize()
+    if world > 1:
+        td.barrier()
+    elapsed = time.perf_counter() - t0
+    sweep_ms, sweep_launches = eng.get_profile()
+    eng.set_option(_lib.OPT_PROFILE, 0)
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=eng.device)
+        td.all_reduce(tt, op=td.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        ms = 1e3 * elapsed / max(1, args.steps)
+        value = world * b * args.steps / elapsed
+        mean_sweeps = float(np.mean(sweeps_seen)) if sweeps_seen else 0.0
+        flops = step_flops(d, r, b, mean_sweeps)
+        out = {
+            "metric": "patches/sec per ONMF minibatch step (d x r dict)",
+            "value": value, "unit": "patches/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: d=%d r=%d batch=%d per GPU, alpha=0 beta=1 sub_iter=%d "
+                                   "stopping_diff=%g, device-drawn H0, (A,B,W) carried"
+                                   % (args.workload, d, r, b, SWEEPS, args.stopping_diff),
+                       "mean_sweeps": mean_sweeps,
+                       "step_tflops_per_gpu": flops / (ms * 1e-3) / 1e12,
+                       "step_frac_of_fp32_mfma_peak": flops / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                       "sync_every": args.sync_every if world > 1 else None},
+        }
+        if sweep_launches > 0:
+            per_launch = 2.0 * r * r * b                      # flops of one sweep launch
+            avg_ms = sweep_ms / sweep_launches
+            ach = per_launch / (avg_ms * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": "code sweep (one launch = one sweep over the batch)",
+                               "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                               "avg_launch_ms": avg_ms, "launches": sweep_launches}
+        if not args.no_cpu_baseline:
+            cols = args.cpu_cols or min(b, 4096)
+            out["cpu_baseline"] = cpu_baseline(d, r, cols)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        td.barrier()
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,141 @@
+/*
+ * onmf_hip.h - C-ABI of libonmf_hip.so: the online-NMF minibatch step on MI355X (gfx950).
+ *
+ * The reference (HanbaekLyu/ONMF_ONTF_NDL) is pure Python and has no FFI of its own; its boundary
+ * for this path is the `Online_NMF` / `Online_NTF` class surface.  Every entry point below names
+ * the reference function it stands in for.  A Python host binds them with ctypes
+ * (onmf_ontf_ndl_amd/_lib.py); nothing in these signatures is a torch type.
+ *
+ * Conventions
+ *   - All matrix pointers are DEVICE pointers to float32, row-major (NumPy C order), owned by the
+ *     caller.  The context owns scratch memory only.
+ *   - Shapes follow the reference: X (d x b, leading dimension ldx >= b), W (d x r), H (r x b),
+ *     A (r x r), B (r x d), C (d x d).
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls enqueue work on it;
+ *     entry points that return host scalars (sweeps_done, dist_trace) synchronise that stream.
+ *   - Return value: ONMF_OK (0) or a negative ONMF_ERR_* code; the text is onmf_last_error(ctx).
+ *     Nothing throws across the ABI.  A context is not thread-safe; use one per GPU/stream.
+ */
+#ifndef ONMF_HIP_H
+#define ONMF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ONMF_OK 0
+#define ONMF_ERR_ARG (-1)       /* bad shape / null pointer / unsupported size          */
+#define ONMF_ERR_HIP (-2)       /* a HIP runtime call failed                             */
+#define ONMF_ERR_NOMEM (-3)     /* scratch allocation failed                             */
+#define ONMF_ERR_TIMEOUT (-4)   /* a bounded device-side wait gave up (dictionary pass)  */
+
+#define ONMF_ABI_VERSION 1
+
+/* coder_mode of onmf_sparse_code */
+#define ONMF_CODER_DAMPED 0 /* reference step 1/(sqrt(i+10)(G_kk+1)), src/onmf.py:257       */
+#define ONMF_CODER_EXACT_CD 1 /* step 1/G_kk, run to a fixed point: the convex problem that   \
+                                 src/ontf.py:79-86 hands to sklearn LassoLars                 */
+
+typedef struct onmf_ctx onmf_ctx;
+
+int onmf_abi_version(void);
+
+/* Scratch owner for one GPU.  No counterpart in the reference (NumPy allocates temporaries). */
+int onmf_create(int device, onmf_ctx** out);
+int onmf_destroy(onmf_ctx* ctx);
+const char* onmf_last_error(onmf_ctx* ctx);
+
+/*
+ * update_code_within_radius(X, W, H0, r=None, alpha, sub_iter, stopping_diff)  src/onmf.py:233-271
+ * and Online_NMF.sparse_code (src/onmf.py:51-90, which calls it with sub_iter=10, stopping_diff=0.01).
+ *   H0 == NULL: H0 ~ U[0,1) from a counter-based device generator keyed by `seed`
+ *               (the reference draws it from NumPy's global generator, onmf.py:245-246; a host
+ *               that needs that exact stream draws it itself and passes H0).
+ *   stopping_diff: the loop ends when sigma_max(H - H_prev)/sigma_max(H_prev) <= stopping_diff
+ *               (spectral norms, onmf.py:265) or after sub_iter sweeps.
+ *   sweeps_done (host int*, nullable), dist_trace (host float[sub_iter], nullable; entries for
+ *               sweeps whose test was decided by bounds alone are set to NaN).
+ *   The radius argument r of the reference is not supported: every caller passes r=None.
+ */
+int onmf_sparse_code(onmf_ctx* ctx, int d, int r, int b, const float* X, int ldx, const float* W,
+                     const float* H0, uint64_t seed, float alpha, int sub_iter,
+                     float stopping_diff, int coder_mode, float* H, int* sweeps_done,
+                     float* dist_trace, void* stream);
+
+/*
+ * Aggregate recursion of Online_NMF.step, src/onmf.py:150-158 (ontf form: src/ontf.py:147-148):
+ *   A_out = (1-w) A_in + w H H^T,  B_out = (1-w) B_in + w H X^T,  [C_out = (1-w) C_in + w X X^T]
+ * with w = t^(-beta) computed by the caller.  C_in/C_out may be NULL (two-aggregate form).
+ * In/out pointers may alias.  A_in/B_in/C_in NULL means zeros.
+ */
+int onmf_aggregate(onmf_ctx* ctx, int d, int r, int b, const float* X, int ldx, const float* H,
+                   double w, const float* A_in, const float* B_in, const float* C_in, float* A_out,
+                   float* B_out, float* C_out, void* stream);
+
+/* Online_NMF.update_dict(W, A, B), src/onmf.py:92-116 (same body: src/ontf.py:91-115). */
+int onmf_update_dict(onmf_ctx* ctx, int d, int r, const float* W_in, const float* A, const float* B,
+                     float* W_out, void* stream);
+
+/*
+ * Online_NMF.step(X, aggregates, W, t), src/onmf.py:119-167: code, aggregates, then the
+ * dictionary pass with the aggregates from BEFORE this step (onmf.py:161).  w = t^(-beta).
+ * H_out may be NULL when the caller does not need the code.  Outputs may alias inputs.
+ */
+int onmf_step(onmf_ctx* ctx, int d, int r, int b, const float* X, int ldx, const float* W_in,
+              const float* A_in, const float* B_in, const float* C_in, const float* H0,
+              uint64_t seed, double w, float alpha, int sub_iter, float stopping_diff,
+              float* H_out, float* A_out, float* B_out, float* C_out, float* W_out,
+              int* sweeps_done, float* dist_trace, void* stream);
+
+/* X_batch = X[:, idx]  (src/onmf.py:214, src/ontf.py:231); idx: device int64[b]. */
+int onmf_gather_columns(onmf_ctx* ctx, int d, int n, const float* X, int ldx, const int64_t* idx,
+                        int b, float* Xb, void* stream);
+
+/*
+ * code[:, idx] += H with NumPy fancy-index semantics (src/onmf.py:221): for a repeated index only
+ * its last occurrence contributes.  idx == NULL means idx = arange(n) (dense add, b == n).
+ */
+int onmf_code_accumulate(onmf_ctx* ctx, int r, int n, float* code, const int64_t* idx, int b,
+                         const float* H, void* stream);
+
+/*
+ * tensorly.unfold(T, mode) for a 3-way tensor (src/ontf.py:204), optionally transposed
+ * (learn_joint_dict, src/ontf.py:207).  T: (n0 x n1 x n2) C order.  out: (n_mode x rest), or its
+ * transpose.
+ */
+int onmf_unfold3(onmf_ctx* ctx, int n0, int n1, int n2, const float* T, int mode, int transpose,
+                 float* out, void* stream);
+
+/* U[0,1) fill, the device stand-in for np.random.rand (src/onmf.py:190, :246). */
+int onmf_fill_uniform(onmf_ctx* ctx, float* out, size_t n, uint64_t seed, void* stream);
+
+/*
+ * Host-side helper of the stopping test: largest eigenvalue (double) of a symmetric positive
+ * semi-definite n x n float matrix in HOST memory.  sigma_max(M)^2 of src/onmf.py:265 is this
+ * value for M M^T.  Touches no GPU.
+ */
+double onmf_host_lambda_max(const float* S_host, int n);
+
+/*
+ * Options (no counterpart in the reference).
+ *   ONMF_OPT_PROFILE       != 0: bracket the sweep kernels of later sparse-code calls with HIP
+ *                          events on the caller's stream; read back with onmf_get_profile.
+ *   ONMF_OPT_EXACT_STOP    != 0: always evaluate the spectral-norm stopping test in full (Gram
+ *                          matrices + eigenvalues) instead of deciding by norm bounds when those
+ *                          are conclusive; dist_trace then holds every dist value.
+ *   ONMF_OPT_SWEEP_KERNEL  0 = pick by shape, 1 = column-per-lane kernel, 2 = MFMA tile kernel.
+ */
+#define ONMF_OPT_PROFILE 1
+#define ONMF_OPT_EXACT_STOP 2
+#define ONMF_OPT_SWEEP_KERNEL 3
+int onmf_set_option(onmf_ctx* ctx, int key, int value);
+/* Summed device time (ms) and number of sweep-kernel launches since the previous call. */
+int onmf_get_profile(onmf_ctx* ctx, double* sweep_ms, int* sweep_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ONMF_HIP_H */

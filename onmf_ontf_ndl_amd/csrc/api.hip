@@ -1,0 +1,472 @@
+// C-ABI entry points of libonmf_hip.so and the host-side control of the ONMF minibatch step
+// (launch order, the sweep loop and its stopping test).  Signatures: include/onmf_hip.h.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+// context helpers
+// ---------------------------------------------------------------------------------------------
+static thread_local std::string g_create_error;
+
+int onmf_fail(onmf_ctx* c, int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_error = buf;
+    return code;
+}
+
+int onmf_reserve(onmf_ctx* c, DevBuf& b, size_t bytes, const char* what) {
+    if (bytes <= b.bytes) return ONMF_OK;
+    if (b.p) {
+        HIP_TRY(c, hipFree(b.p));      // synchronises the device: nothing in flight uses it after
+        b.p = nullptr;
+        b.bytes = 0;
+    }
+    const size_t want = (bytes + 255) & ~(size_t)255;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+        b.p = nullptr;
+        return onmf_fail(c, ONMF_ERR_NOMEM, "hipMalloc of %zu bytes for %s failed: %s", want, what,
+                         hipGetErrorString(e));
+    }
+    b.bytes = want;
+    return ONMF_OK;
+}
+
+int onmf_reserve_pinned(onmf_ctx* c, size_t bytes) {
+    if (bytes <= c->pinned_bytes) return ONMF_OK;
+    if (c->pinned) {
+        HIP_TRY(c, hipHostFree(c->pinned));
+        c->pinned = nullptr;
+        c->pinned_bytes = 0;
+    }
+    const size_t want = (bytes + 4095) & ~(size_t)4095;
+    hipError_t e = hipHostMalloc(&c->pinned, want, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        c->pinned = nullptr;
+        return onmf_fail(c, ONMF_ERR_NOMEM, "hipHostMalloc of %zu bytes failed: %s", want,
+                         hipGetErrorString(e));
+    }
+    c->pinned_bytes = want;
+    return ONMF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// largest eigenvalue of a symmetric PSD matrix: Lanczos with full re-orthogonalisation, the
+// tridiagonal's top eigenvalue by Sturm-sequence bisection; all in double.
+// ---------------------------------------------------------------------------------------------
+static double tridiag_top(const std::vector<double>& a, const std::vector<double>& b, int m) {
+    double lo = std::numeric_limits<double>::infinity(), hi = -lo;
+    for (int i = 0; i < m; ++i) {
+        const double off = (i > 0 ? std::fabs(b[i - 1]) : 0.0) + (i + 1 < m ? std::fabs(b[i]) : 0.0);
+        lo = std::min(lo, a[i] - off);
+        hi = std::max(hi, a[i] + off);
+    }
+    if (m == 1) return a[0];
+    auto below = [&](double x) {   // number of eigenvalues < x
+        int cnt = 0;
+        double q = a[0] - x;
+        if (q < 0) ++cnt;
+        for (int i = 1; i < m; ++i) {
+            if (q == 0.0) q = 1e-300;
+            q = a[i] - x - b[i - 1] * b[i - 1] / q;
+            if (q < 0) ++cnt;
+        }
+        return cnt;
+    };
+    for (int it = 0; it < 200 && hi - lo > 1e-16 * std::max(std::fabs(hi), std::fabs(lo)); ++it) {
+        const double mid = 0.5 * (lo + hi);
+        if (below(mid) >= m) hi = mid; else lo = mid;
+    }
+    return 0.5 * (lo + hi);
+}
+
+double host_lambda_max(const float* S, int n) {
+    if (n <= 0) return 0.0;
+    if (n == 1) return (double)S[0];
+    double fro = 0.0;
+    for (size_t i = 0; i < (size_t)n * n; ++i) fro += (double)S[i] * S[i];
+    if (!(fro > 0.0)) return (fro == 0.0) ? 0.0 : std::numeric_limits<double>::quiet_NaN();
+    const int mmax = n;
+    std::vector<double> V((size_t)(mmax + 1) * n), w(n), al, be;
+    // deterministic start vector with a component along every coordinate
+    double nv = 0.0;
+    for (int i = 0; i < n; ++i) {
+        V[i] = 1.0 + 0.5 * std::sin(12.9898 * (i + 1));
+        nv += V[i] * V[i];
+    }
+    nv = std::sqrt(nv);
+    for (int i = 0; i < n; ++i) V[i] /= nv;
+    double theta = 0.0, prev = -1.0;
+    int calm = 0;
+    for (int j = 0; j < mmax; ++j) {
+        const double* vj = &V[(size_t)j * n];
+        for (int i = 0; i < n; ++i) {
+            const float* row = S + (size_t)i * n;
+            double acc = 0.0;
+            for (int k = 0; k < n; ++k) acc += (double)row[k] * vj[k];
+            w[i] = acc;
+        }
+        double a = 0.0;
+        for (int i = 0; i < n; ++i) a += w[i] * vj[i];
+        al.push_back(a);
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int l = 0; l <= j; ++l) {
+                const double* vl = &V[(size_t)l * n];
+                double c = 0.0;
+                for (int i = 0; i < n; ++i) c += w[i] * vl[i];
+                for (int i = 0; i < n; ++i) w[i] -= c * vl[i];
+            }
+        }
+        double bn = 0.0;
+        for (int i = 0; i < n; ++i) bn += w[i] * w[i];
+        bn = std::sqrt(bn);
+        theta = tridiag_top(al, be, j + 1);
+        if (bn <= 1e-14 * std::sqrt(fro) || j + 1 == mmax) break;
+        if (n > 48) {       // small matrices run the full n steps (exact); larger ones stop on stagnation
+            if (std::fabs(theta - prev) <= 4e-16 * std::fabs(theta)) ++calm; else calm = 0;
+            if (calm >= 6 && j >= 24) break;
+        }
+        prev = theta;
+        be.push_back(bn);
+        double* vn = &V[(size_t)(j + 1) * n];
+        for (int i = 0; i < n; ++i) vn[i] = w[i] / bn;
+    }
+    return theta;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ABI
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+int onmf_abi_version(void) { return ONMF_ABI_VERSION; }
+
+double onmf_host_lambda_max(const float* S_host, int n) { return host_lambda_max(S_host, n); }
+
+int onmf_create(int device, onmf_ctx** out) {
+    if (!out) return onmf_fail(nullptr, ONMF_ERR_ARG, "onmf_create: out is null");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return onmf_fail(nullptr, ONMF_ERR_HIP, "onmf_create: no HIP device (%s)", hipGetErrorString(e));
+    if (device < 0 || device >= count)
+        return onmf_fail(nullptr, ONMF_ERR_ARG, "onmf_create: device %d out of range (%d devices)", device, count);
+    e = hipSetDevice(device);
+    if (e != hipSuccess)
+        return onmf_fail(nullptr, ONMF_ERR_HIP, "hipSetDevice(%d): %s", device, hipGetErrorString(e));
+    onmf_ctx* c = new (std::nothrow) onmf_ctx();
+    if (!c) return onmf_fail(nullptr, ONMF_ERR_NOMEM, "onmf_create: out of host memory");
+    c->device = device;
+    *out = c;
+    return ONMF_OK;
+}
+
+int onmf_destroy(onmf_ctx* c) {
+    if (!c) return ONMF_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    DevBuf* bufs[] = {&c->slab, &c->cm, &c->gram, &c->hbuf[0], &c->hbuf[1], &c->stats, &c->small,
+                      &c->qt, &c->sync, &c->idx, &c->dbuf};
+    for (DevBuf* b : bufs)
+        if (b->p) (void)hipFree(b->p);
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    for (hipEvent_t ev : c->ev) (void)hipEventDestroy(ev);
+    delete c;
+    return ONMF_OK;
+}
+
+const char* onmf_last_error(onmf_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int onmf_set_option(onmf_ctx* c, int key, int value) {
+    if (!c) return ONMF_ERR_ARG;
+    switch (key) {
+        case ONMF_OPT_PROFILE: c->profile = value; return ONMF_OK;
+        case ONMF_OPT_EXACT_STOP: c->exact_stop = value; return ONMF_OK;
+        case ONMF_OPT_SWEEP_KERNEL: c->sweep_kernel = value; return ONMF_OK;
+        default: return onmf_fail(c, ONMF_ERR_ARG, "onmf_set_option: unknown key %d", key);
+    }
+}
+
+int onmf_get_profile(onmf_ctx* c, double* sweep_ms, int* sweep_launches) {
+    if (!c) return ONMF_ERR_ARG;
+    double total = 0.0;
+    const int pairs = c->ev_used / 2;
+    for (int i = 0; i < pairs; ++i) {
+        float ms = 0.f;
+        HIP_TRY(c, hipEventSynchronize(c->ev[2 * i + 1]));
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[2 * i], c->ev[2 * i + 1]));
+        total += ms;
+    }
+    if (sweep_ms) *sweep_ms = total;
+    if (sweep_launches) *sweep_launches = pairs;
+    c->ev_used = 0;
+    return ONMF_OK;
+}
+
+}  // extern "C"
+
+static int profile_mark(onmf_ctx* c, hipStream_t s) {
+    if (!c->profile) return ONMF_OK;
+    if (c->ev_used >= (int)c->ev.size()) {
+        hipEvent_t e;
+        HIP_TRY(c, hipEventCreate(&e));
+        c->ev.push_back(e);
+    }
+    HIP_TRY(c, hipEventRecord(c->ev[c->ev_used++], s));
+    return ONMF_OK;
+}
+
+// The reference's loop test is `dist > stopping_diff` with dist = s1 / s0 evaluated in floating
+// point (src/onmf.py:252, :265): NaN (0/0) ends the loop, +inf (x/0) continues it.
+static bool keep_sweeping(double dist, double tol) { return dist > tol; }
+
+static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, int ldx,
+                            const float* W, const float* H0, uint64_t seed, float alpha,
+                            int sub_iter, float stopping_diff, int coder_mode, float* H,
+                            int* sweeps_done, float* dist_trace, hipStream_t s) {
+    if (d <= 0 || r <= 0 || b <= 0 || !X || !W || !H || ldx < b || sub_iter < 0)
+        return onmf_fail(c, ONMF_ERR_ARG, "sparse_code: bad arguments (d=%d r=%d b=%d ldx=%d)", d, r, b, ldx);
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t rb = (size_t)r * b;
+    ONMF_TRY(onmf_reserve(c, c->gram, (size_t)r * r * sizeof(float), "Gm"));
+    ONMF_TRY(onmf_reserve(c, c->cm, rb * sizeof(float), "Cm"));
+    ONMF_TRY(onmf_reserve(c, c->hbuf[0], rb * sizeof(float), "code buffer"));
+    ONMF_TRY(onmf_reserve(c, c->hbuf[1], rb * sizeof(float), "code buffer"));
+    const int max_groups = (b + 15) / 16 + 8;
+    ONMF_TRY(onmf_reserve(c, c->stats, (size_t)max_groups * 2 * sizeof(double), "sweep statistics"));
+    ONMF_TRY(onmf_reserve_pinned(c, std::max((size_t)max_groups * 2 * sizeof(double),
+                                             (size_t)2 * r * r * sizeof(float))));
+    float* Gm = (float*)c->gram.p;
+    float* Cm = (float*)c->cm.p;
+    // Gm = W^T W,  Cm = W^T X   (src/onmf.py:242-243)
+    ONMF_TRY(launch_gemm(c, true, true, r, r, d, W, r, W, r, 1.f, 0.f, nullptr, Gm, r, s));
+    ONMF_TRY(launch_gemm(c, true, true, r, b, d, W, r, X, ldx, 1.f, 0.f, nullptr, Cm, b, s));
+    float* cur = (float*)c->hbuf[0].p;
+    float* nxt = (float*)c->hbuf[1].p;
+    if (H0) {
+        HIP_TRY(c, hipMemcpyAsync(cur, H0, rb * sizeof(float), hipMemcpyDeviceToDevice, s));
+    } else {
+        ONMF_TRY(launch_fill_uniform(cur, rb, seed, s));
+    }
+    const double tol = (double)stopping_diff;
+    const double rank_cap = (double)std::min(r, b);
+    int done = 0;
+    double dist = 1.0;      // src/onmf.py:251
+    while (done < sub_iter && keep_sweeping(dist, tol)) {
+        const float damp = (float)std::sqrt((double)done + 10.0);
+        int groups = 0;
+        ONMF_TRY(profile_mark(c, s));
+        ONMF_TRY(launch_sweep(c, r, b, Gm, Cm, cur, nxt, alpha, damp,
+                              coder_mode == ONMF_CODER_EXACT_CD, (double*)c->stats.p, &groups, s));
+        ONMF_TRY(profile_mark(c, s));
+        HIP_TRY(c, hipMemcpyAsync(c->pinned, c->stats.p, (size_t)groups * 2 * sizeof(double),
+                                  hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        const double* hs = (const double*)c->pinned;
+        double dsum = 0.0, hsum = 0.0;
+        for (int g = 0; g < groups; ++g) {
+            dsum += hs[2 * g];
+            hsum += hs[2 * g + 1];
+        }
+        // Decide `dist > tol` from Frobenius norms when they settle it:
+        //   s1 in [fD / sqrt(rank), fD],  s0 in [fH / sqrt(rank), fH]   (fD, fH Frobenius norms)
+        bool decided = false;
+        double shown = std::numeric_limits<double>::quiet_NaN();
+        const double fD = std::sqrt(dsum), fH = std::sqrt(hsum);
+        if (coder_mode == ONMF_CODER_EXACT_CD) {
+            // fixed-point iteration of the convex problem: stop on the relative Frobenius change
+            dist = (hsum == 0.0) ? (dsum == 0.0 ? 0.0 : std::numeric_limits<double>::infinity())
+                                 : fD / fH;
+            decided = true;
+            shown = dist;
+        } else if (!c->exact_stop) {
+            if (hsum == 0.0) {                    // s0 == 0: dist is NaN (stop) or +inf (continue)
+                dist = (dsum == 0.0) ? std::numeric_limits<double>::quiet_NaN()
+                                     : std::numeric_limits<double>::infinity();
+                decided = true;
+                shown = dist;
+            } else if (dsum == 0.0) {
+                dist = 0.0;
+                decided = true;
+                shown = 0.0;
+            } else if (tol < 0.0) {
+                dist = 1.0;                       // any positive value compares the same way
+                decided = true;
+            } else {
+                const double lower = (fD / std::sqrt(rank_cap)) / fH * (1.0 - 1e-4);
+                const double upper = fD / (fH / std::sqrt(rank_cap)) * (1.0 + 1e-4);
+                if (lower > tol) { dist = lower; decided = true; }
+                else if (upper <= tol) { dist = upper; decided = true; }
+            }
+        }
+        if (!decided) {
+            // full test: sigma_max via the r x r Gram matrices of (H - H_prev) and H_prev
+            ONMF_TRY(onmf_reserve(c, c->dbuf, rb * sizeof(float), "code difference"));
+            ONMF_TRY(onmf_reserve(c, c->small, (size_t)2 * r * r * sizeof(float), "stop-test Grams"));
+            float* D = (float*)c->dbuf.p;
+            float* G1 = (float*)c->small.p;
+            float* G0 = G1 + (size_t)r * r;
+            ONMF_TRY(launch_sub(D, nxt, cur, rb, s));
+            ONMF_TRY(launch_gemm(c, false, false, r, r, b, D, b, D, b, 1.f, 0.f, nullptr, G1, r, s));
+            ONMF_TRY(launch_gemm(c, false, false, r, r, b, cur, b, cur, b, 1.f, 0.f, nullptr, G0, r, s));
+            HIP_TRY(c, hipMemcpyAsync(c->pinned, G1, (size_t)2 * r * r * sizeof(float),
+                                      hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipStreamSynchronize(s));
+            const float* hg = (const float*)c->pinned;
+            const double l1 = host_lambda_max(hg, r);
+            const double l0 = host_lambda_max(hg + (size_t)r * r, r);
+            dist = std::sqrt(std::max(l1, 0.0)) / std::sqrt(std::max(l0, 0.0));
+            shown = dist;
+        }
+        if (dist_trace) dist_trace[done] = (float)shown;
+        std::swap(cur, nxt);
+        ++done;
+    }
+    HIP_TRY(c, hipMemcpyAsync(H, cur, rb * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (sweeps_done) *sweeps_done = done;
+    if (dist_trace)
+        for (int i = done; i < sub_iter; ++i) dist_trace[i] = std::numeric_limits<float>::quiet_NaN();
+    return ONMF_OK;
+}
+
+static int aggregate_impl(onmf_ctx* c, int d, int r, int b, const float* X, int ldx, const float* H,
+                          double w, const float* A_in, const float* B_in, const float* C_in,
+                          float* A_out, float* B_out, float* C_out, hipStream_t s) {
+    if (d <= 0 || r <= 0 || b <= 0 || !X || !H || !A_out || !B_out || ldx < b)
+        return onmf_fail(c, ONMF_ERR_ARG, "aggregate: bad arguments");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const float fw = (float)w, keep = (float)(1.0 - w);
+    // A_out = (1-w) A_in + w H H^T ; B_out = (1-w) B_in + w H X^T   (src/onmf.py:155-156)
+    ONMF_TRY(launch_gemm(c, false, false, r, r, b, H, b, H, b, fw, A_in ? keep : 0.f, A_in, A_out, r, s));
+    ONMF_TRY(launch_gemm(c, false, false, r, d, b, H, b, X, ldx, fw, B_in ? keep : 0.f, B_in, B_out, d, s));
+    if (C_out)   // C_out = (1-w) C_in + w X X^T   (src/onmf.py:158)
+        ONMF_TRY(launch_gemm(c, false, false, d, d, b, X, ldx, X, ldx, fw, C_in ? keep : 0.f, C_in, C_out, d, s));
+    return ONMF_OK;
+}
+
+static int dict_check(onmf_ctx* c, int r, int d, hipStream_t s) {
+    const int nwg = (d + 63) / 64;
+    if (nwg <= 1) return ONMF_OK;
+    const size_t off = (size_t)r * nwg * sizeof(unsigned long long);
+    ONMF_TRY(onmf_reserve_pinned(c, 64));
+    HIP_TRY(c, hipMemcpyAsync(c->pinned, (char*)c->sync.p + off, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    if (*(int*)c->pinned != 0)
+        return onmf_fail(c, ONMF_ERR_TIMEOUT,
+                         "update_dict: a workgroup waited more than 2 s for the other %d (not co-resident?)", nwg - 1);
+    return ONMF_OK;
+}
+
+extern "C" {
+
+int onmf_sparse_code(onmf_ctx* c, int d, int r, int b, const float* X, int ldx, const float* W,
+                     const float* H0, uint64_t seed, float alpha, int sub_iter, float stopping_diff,
+                     int coder_mode, float* H, int* sweeps_done, float* dist_trace, void* stream) {
+    if (!c) return ONMF_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    ONMF_TRY(sparse_code_impl(c, d, r, b, X, ldx, W, H0, seed, alpha, sub_iter, stopping_diff,
+                              coder_mode, H, sweeps_done, dist_trace, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    return ONMF_OK;
+}
+
+int onmf_aggregate(onmf_ctx* c, int d, int r, int b, const float* X, int ldx, const float* H, double w,
+                   const float* A_in, const float* B_in, const float* C_in, float* A_out, float* B_out,
+                   float* C_out, void* stream) {
+    if (!c) return ONMF_ERR_ARG;
+    return aggregate_impl(c, d, r, b, X, ldx, H, w, A_in, B_in, C_in, A_out, B_out, C_out,
+                          (hipStream_t)stream);
+}
+
+int onmf_update_dict(onmf_ctx* c, int d, int r, const float* W_in, const float* A, const float* B,
+                     float* W_out, void* stream) {
+    if (!c) return ONMF_ERR_ARG;
+    if (d <= 0 || r <= 0 || !W_in || !A || !B || !W_out)
+        return onmf_fail(c, ONMF_ERR_ARG, "update_dict: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(c, hipSetDevice(c->device));
+    ONMF_TRY(launch_dict_pass(c, d, r, W_in, A, B, W_out, s));
+    return dict_check(c, r, d, s);
+}
+
+int onmf_step(onmf_ctx* c, int d, int r, int b, const float* X, int ldx, const float* W_in,
+              const float* A_in, const float* B_in, const float* C_in, const float* H0, uint64_t seed,
+              double w, float alpha, int sub_iter, float stopping_diff, float* H_out, float* A_out,
+              float* B_out, float* C_out, float* W_out, int* sweeps_done, float* dist_trace,
+              void* stream) {
+    if (!c) return ONMF_ERR_ARG;
+    if (!W_in || !A_in || !B_in || !A_out || !B_out || !W_out)
+        return onmf_fail(c, ONMF_ERR_ARG, "step: null state pointer");
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(c, hipSetDevice(c->device));
+    float* H = H_out;
+    if (!H) {
+        // hbuf[] are the sweep ping-pong buffers, so the code gets its own scratch
+        ONMF_TRY(onmf_reserve(c, c->dbuf, (size_t)r * b * sizeof(float) * 2, "step code"));
+        H = (float*)c->dbuf.p + (size_t)r * b;
+    }
+    // order keeps every in-place aliasing legal: code (reads W_in) -> dictionary pass with the OLD
+    // aggregates (src/onmf.py:161) -> aggregates
+    ONMF_TRY(sparse_code_impl(c, d, r, b, X, ldx, W_in, H0, seed, alpha, sub_iter, stopping_diff,
+                              ONMF_CODER_DAMPED, H, sweeps_done, dist_trace, s));
+    ONMF_TRY(launch_dict_pass(c, d, r, W_in, A_in, B_in, W_out, s));
+    ONMF_TRY(aggregate_impl(c, d, r, b, X, ldx, H, w, A_in, B_in, C_in, A_out, B_out, C_out, s));
+    return dict_check(c, r, d, s);
+}
+
+int onmf_gather_columns(onmf_ctx* c, int d, int n, const float* X, int ldx, const int64_t* idx, int b,
+                        float* Xb, void* stream) {
+    if (!c) return ONMF_ERR_ARG;
+    if (d <= 0 || n <= 0 || b <= 0 || !X || !idx || !Xb || ldx < n)
+        return onmf_fail(c, ONMF_ERR_ARG, "gather_columns: bad arguments");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (launch_gather_columns(d, n, X, ldx, (const long long*)idx, b, Xb, (hipStream_t)stream) != ONMF_OK)
+        return onmf_fail(c, ONMF_ERR_HIP, "gather_columns: launch failed");
+    return ONMF_OK;
+}
+
+int onmf_code_accumulate(onmf_ctx* c, int r, int n, float* code, const int64_t* idx, int b,
+                         const float* H, void* stream) {
+    if (!c) return ONMF_ERR_ARG;
+    if (r <= 0 || n <= 0 || b <= 0 || !code || !H || (!idx && b != n))
+        return onmf_fail(c, ONMF_ERR_ARG, "code_accumulate: bad arguments");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    if (!idx) {
+        if (launch_axpy(code, H, 1.0f, (size_t)r * n, s) != ONMF_OK)
+            return onmf_fail(c, ONMF_ERR_HIP, "code_accumulate: launch failed");
+        return ONMF_OK;
+    }
+    return launch_scatter_add_last(c, r, n, code, (const long long*)idx, b, H, s);
+}
+
+int onmf_unfold3(onmf_ctx* c, int n0, int n1, int n2, const float* T, int mode, int transpose,
+                 float* out, void* stream) {
+    if (!c) return ONMF_ERR_ARG;
+    if (n0 <= 0 || n1 <= 0 || n2 <= 0 || !T || !out || mode < 0 || mode > 2)
+        return onmf_fail(c, ONMF_ERR_ARG, "unfold3: bad arguments");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (launch_unfold3(n0, n1, n2, T, mode, transpose, out, (hipStream_t)stream) != ONMF_OK)
+        return onmf_fail(c, ONMF_ERR_HIP, "unfold3: launch failed");
+    return ONMF_OK;
+}
+
+int onmf_fill_uniform(onmf_ctx* c, float* out, size_t n, uint64_t seed, void* stream) {
+    if (!c) return ONMF_ERR_ARG;
+    if (!out && n) return onmf_fail(c, ONMF_ERR_ARG, "fill_uniform: null output");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (launch_fill_uniform(out, n, seed, (hipStream_t)stream) != ONMF_OK)
+        return onmf_fail(c, ONMF_ERR_HIP, "fill_uniform: launch failed");
+    return ONMF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,73 @@
+// Gauss-Seidel code sweeps of the ONMF sparse-code solve on gfx950 (src/onmf.py:252-263 of the
+// reference):  for k in order:  g = Gm[k,:] . h - Cm[k] + alpha ;  h[k] = max(0, h[k] - g * step_k)
+// with step_k = 1 / (sqrt(i+10) * (Gm[k,k] + 1)).  Columns of H are independent.
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// Generic kernel: one column per lane, the column's h in LDS ([r][64], conflict-free), rows of
+// Gm read through wave-uniform (scalar) loads.  Any r with r*256 B <= 160 KB.  It is the
+// fallback for shapes the tiled kernel does not cover and the cross-check for it.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void sweep_column_kernel(int r, int b, const float* __restrict__ Gm,
+                                                          const float* __restrict__ Cm,
+                                                          const float* __restrict__ Hin,
+                                                          float* __restrict__ Hout, float alpha,
+                                                          float damp, int exact_cd,
+                                                          double* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) float hs[];
+    const int lane = threadIdx.x;
+    const int c = blockIdx.x * 64 + lane;
+    const bool valid = c < b;
+    for (int k = 0; k < r; ++k) hs[k * 64 + lane] = valid ? Hin[(size_t)k * b + c] : 0.f;
+    float dsum = 0.f, hsum = 0.f;
+    for (int k = 0; k < r; ++k) {
+        const float* __restrict__ gk = Gm + (size_t)k * r;
+        float dot = 0.f;
+        for (int j = 0; j < r; ++j) dot = fmaf(gk[j], hs[j * 64 + lane], dot);
+        const float gkk = gk[k];
+        const float step = exact_cd ? (gkk > 0.f ? 1.0f / gkk : 0.f) : 1.0f / (damp * (gkk + 1.0f));
+        const float hold = hs[k * 64 + lane];
+        const float cm = valid ? Cm[(size_t)k * b + c] : 0.f;
+        const float grad = dot - cm + alpha;
+        const float hnew = valid ? fmaxf(hold - grad * step, 0.f) : 0.f;
+        hs[k * 64 + lane] = hnew;
+        const float dl = hnew - hold;
+        dsum = fmaf(dl, dl, dsum);
+        hsum = fmaf(hold, hold, hsum);
+        if (valid) Hout[(size_t)k * b + c] = hnew;
+    }
+    // wave reduction (fixed tree), one pair of doubles per workgroup
+    double ds = dsum, hh = hsum;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        ds += __shfl_xor(ds, off);
+        hh += __shfl_xor(hh, off);
+    }
+    if (lane == 0) {
+        stats[2 * blockIdx.x + 0] = ds;
+        stats[2 * blockIdx.x + 1] = hh;
+    }
+}
+
+}  // namespace
+
+int launch_sweep(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm, const float* Hin,
+                 float* Hout, float alpha, float damp, int exact_cd, double* stats, int* n_groups,
+                 hipStream_t s) {
+    const size_t lds = (size_t)r * 64 * sizeof(float);
+    if (lds > 160 * 1024) return onmf_fail(c, ONMF_ERR_ARG, "sweep: r=%d needs %zu B of LDS", r, lds);
+    static size_t attr_bytes = 0;
+    if (lds > attr_bytes) {
+        HIP_TRY(c, hipFuncSetAttribute((const void*)sweep_column_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_bytes = lds;
+    }
+    const int groups = (b + 63) / 64;
+    *n_groups = groups;
+    hipLaunchKernelGGL(sweep_column_kernel, dim3(groups), dim3(64), lds, s, r, b, Gm, Cm, Hin, Hout,
+                       alpha, damp, exact_cd, stats);
+    HIP_TRY(c, hipGetLastError());
+    return ONMF_OK;
+}

@@ -1,0 +1,87 @@
+"""Multi-GPU operation of the ONMF step: one process per GPU, ``torch.distributed`` (RCCL on ROCm).
+
+The reference is single-process; the only quantities that couple minibatch columns are the sums
+H H^T and H X^T (src/onmf.py:155-156) and the replicated dictionary.  Two ways to use several GPUs:
+
+* independent streams, periodic averaging (``average_state``): every rank runs its own patch stream
+  with its own (W, A, B) and, every few steps, the ranks all-reduce the packed state [A | B | W] and
+  divide by the world size.  Averages of nonnegative matrices with column norms <= 1 stay in that
+  set, so W needs no re-projection.  One collective of r*r + 2*r*d floats per exchange.
+* one large minibatch split by columns (``allreduce_partial_aggregates``): each rank codes its slice
+  and the partial sums are added before the (1-w, w) recursion - equal to the reference run on the
+  concatenated batch up to summation order.
+
+Both helpers work on any tensor device: with the ``gloo`` backend hand them CPU tensors.
+"""
+from __future__ import annotations
+
+import os
+
+
+def init_from_env(backend=None):
+    """Initialise the default process group from RANK / WORLD_SIZE / MASTER_* if there is one."""
+    import torch
+    import torch.distributed as td
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return 0, 1, 0
+    rank = int(os.environ["RANK"])
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if not td.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            td.init_process_group(backend=backend, device_id=torch.device("cuda", local))
+        else:
+            td.init_process_group(backend=backend)
+    return rank, world, local
+
+
+def pack_state(W, A, B):
+    """[A | B | W] as one contiguous vector (one collective instead of three)."""
+    import torch
+    return torch.cat([A.reshape(-1), B.reshape(-1), W.reshape(-1)])
+
+
+def unpack_state(flat, d, r):
+    a, b = r * r, r * d
+    A = flat[:a].reshape(r, r)
+    B = flat[a:a + b].reshape(r, d)
+    W = flat[a + b:a + b + d * r].reshape(d, r)
+    return W, A, B
+
+
+def average_state(W, A, B, group=None):
+    """All-reduce(SUM) of the packed state, divided by the world size. Returns new (W, A, B)."""
+    import torch.distributed as td
+    if not (td.is_available() and td.is_initialized()) or td.get_world_size(group) == 1:
+        return W, A, B
+    d, r = W.shape
+    flat = pack_state(W, A, B)
+    td.all_reduce(flat, op=td.ReduceOp.SUM, group=group)
+    flat /= td.get_world_size(group)
+    W1, A1, B1 = unpack_state(flat, d, r)
+    return W1.contiguous(), A1.contiguous(), B1.contiguous()
+
+
+def allreduce_partial_aggregates(HHt, HXt, group=None):
+    """Sum the per-rank partial products H_g H_g^T and H_g X_g^T in place (one collective)."""
+    import torch
+    import torch.distributed as td
+    if not (td.is_available() and td.is_initialized()) or td.get_world_size(group) == 1:
+        return HHt, HXt
+    flat = torch.cat([HHt.reshape(-1), HXt.reshape(-1)])
+    td.all_reduce(flat, op=td.ReduceOp.SUM, group=group)
+    n = HHt.numel()
+    HHt.copy_(flat[:n].reshape(HHt.shape))
+    HXt.copy_(flat[n:].reshape(HXt.shape))
+    return HHt, HXt
+
+
+def split_columns(n, rank, world):
+    """Column range [lo, hi) of rank's slice when n columns are split as evenly as possible."""
+    base, extra = divmod(n, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)

@@ -1,0 +1,193 @@
+"""Host-side driver of the HIP library on torch-ROCm tensors (device memory + streams only).
+
+One ``Engine`` per GPU owns a library context (scratch buffers).  Every method takes and returns
+float32 ``torch`` tensors on that GPU; the facades in ``onmf.py`` / ``ontf.py`` convert to and from
+whatever the caller handed in.  All arithmetic happens in libonmf_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+_engines = {}
+
+
+def get_engine(device=None):
+    """Engine for a GPU (default: torch's current device)."""
+    import torch
+    if not torch.cuda.is_available():
+        raise _lib.OnmfLibraryError("onmf_ontf_ndl_amd needs a ROCm GPU: torch.cuda.is_available() "
+                                    "is False and there is no CPU path")
+    if device is None:
+        index = torch.cuda.current_device()
+    else:
+        dev = torch.device(device)
+        index = dev.index if dev.index is not None else torch.cuda.current_device()
+    eng = _engines.get(index)
+    if eng is None:
+        eng = _engines[index] = Engine(index)
+    return eng
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class Engine:
+    def __init__(self, index):
+        import torch
+        self.torch = torch
+        self.lib = _lib.load()
+        self.index = int(index)
+        self.device = torch.device("cuda", self.index)
+        ctx = C.c_void_p()
+        rc = self.lib.onmf_create(self.index, C.byref(ctx))
+        _lib.check(rc, None, "onmf_create")
+        self.ctx = ctx
+        self._seed_counter = 0
+
+    def __del__(self):
+        try:
+            if getattr(self, "ctx", None):
+                self.lib.onmf_destroy(self.ctx)
+                self.ctx = None
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ plumbing
+    def stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def dev(self, a, dtype=None):
+        """numpy array / torch tensor -> contiguous float32 tensor on this GPU (no copy if already so)."""
+        torch = self.torch
+        dtype = dtype or torch.float32
+        if isinstance(a, torch.Tensor):
+            return a.to(device=self.device, dtype=dtype).contiguous()
+        arr = np.ascontiguousarray(a)
+        return torch.from_numpy(arr).to(device=self.device, dtype=dtype).contiguous()
+
+    def empty(self, *shape):
+        return self.torch.empty(*shape, dtype=self.torch.float32, device=self.device)
+
+    def zeros(self, *shape):
+        return self.torch.zeros(*shape, dtype=self.torch.float32, device=self.device)
+
+    def next_seed(self, base=0):
+        self._seed_counter += 1
+        return (int(base) * 0x9E3779B97F4A7C15 + self._seed_counter) & 0xFFFFFFFFFFFFFFFF
+
+    def set_option(self, key, value):
+        _lib.check(self.lib.onmf_set_option(self.ctx, int(key), int(value)), self.ctx, "onmf_set_option")
+
+    def get_profile(self):
+        ms, n = C.c_double(0.0), C.c_int(0)
+        _lib.check(self.lib.onmf_get_profile(self.ctx, C.byref(ms), C.byref(n)), self.ctx,
+                   "onmf_get_profile")
+        return ms.value, n.value
+
+    # ------------------------------------------------------------------ the path
+    def sparse_code(self, X, W, H0=None, alpha=0.0, sub_iter=10, stopping_diff=0.01, seed=None,
+                    mode=_lib.CODER_DAMPED):
+        """H (r x b), sweeps run, per-sweep dist (NaN where bounds decided) - onmf.py:233-271."""
+        d, b = X.shape
+        r = W.shape[1]
+        if W.shape[0] != d:
+            raise ValueError("W has %d rows, X has %d" % (W.shape[0], d))
+        if H0 is not None and tuple(H0.shape) != (r, b):
+            raise ValueError("H0 must be (%d, %d)" % (r, b))
+        H = self.empty(r, b)
+        sweeps = C.c_int(0)
+        trace = (C.c_float * max(1, int(sub_iter)))()
+        if seed is None:
+            seed = self.next_seed()
+        rc = self.lib.onmf_sparse_code(self.ctx, d, r, b, _ptr(X), X.stride(0), _ptr(W), _ptr(H0),
+                                       C.c_uint64(seed), float(alpha), int(sub_iter),
+                                       float(stopping_diff), int(mode), _ptr(H), C.byref(sweeps),
+                                       trace, self.stream())
+        _lib.check(rc, self.ctx, "onmf_sparse_code")
+        return H, sweeps.value, np.array(trace[:sweeps.value], dtype=np.float64)
+
+    def aggregate(self, X, H, w, A, B, Cagg=None, want_c=False):
+        d, b = X.shape
+        r = H.shape[0]
+        A1, B1 = self.empty(r, r), self.empty(r, d)
+        C1 = self.empty(d, d) if want_c else None
+        rc = self.lib.onmf_aggregate(self.ctx, d, r, b, _ptr(X), X.stride(0), _ptr(H), float(w),
+                                     _ptr(A), _ptr(B), _ptr(Cagg), _ptr(A1), _ptr(B1), _ptr(C1),
+                                     self.stream())
+        _lib.check(rc, self.ctx, "onmf_aggregate")
+        return A1, B1, C1
+
+    def update_dict(self, W, A, B):
+        d, r = W.shape
+        if tuple(A.shape) != (r, r) or tuple(B.shape) != (r, d):
+            raise ValueError("update_dict: A must be (r,r) and B (r,d)")
+        W1 = self.empty(d, r)
+        rc = self.lib.onmf_update_dict(self.ctx, d, r, _ptr(W), _ptr(A), _ptr(B), _ptr(W1),
+                                       self.stream())
+        _lib.check(rc, self.ctx, "onmf_update_dict")
+        return W1
+
+    def step(self, X, A, B, Cagg, W, w, alpha=0.0, H0=None, seed=None, sub_iter=10,
+             stopping_diff=0.01, want_code=True):
+        """One minibatch step (onmf.py:119-167). Returns H1, A1, B1, C1, W1, sweeps, dist."""
+        d, b = X.shape
+        r = W.shape[1]
+        A1, B1, W1 = self.empty(r, r), self.empty(r, d), self.empty(d, r)
+        C1 = self.empty(d, d) if Cagg is not None else None
+        H = self.empty(r, b) if want_code else None
+        sweeps = C.c_int(0)
+        trace = (C.c_float * max(1, int(sub_iter)))()
+        if seed is None:
+            seed = self.next_seed()
+        rc = self.lib.onmf_step(self.ctx, d, r, b, _ptr(X), X.stride(0), _ptr(W), _ptr(A), _ptr(B),
+                                _ptr(Cagg), _ptr(H0), C.c_uint64(seed), float(w), float(alpha),
+                                int(sub_iter), float(stopping_diff), _ptr(H), _ptr(A1), _ptr(B1),
+                                _ptr(C1), _ptr(W1), C.byref(sweeps), trace, self.stream())
+        _lib.check(rc, self.ctx, "onmf_step")
+        return H, A1, B1, C1, W1, sweeps.value, np.array(trace[:sweeps.value], dtype=np.float64)
+
+    # ------------------------------------------------------------------ around the path
+    def gather_columns(self, X, idx):
+        d, n = X.shape
+        idx = self.dev(idx, self.torch.int64)
+        b = idx.numel()
+        Xb = self.empty(d, b)
+        rc = self.lib.onmf_gather_columns(self.ctx, d, n, _ptr(X), X.stride(0), _ptr(idx), b,
+                                          _ptr(Xb), self.stream())
+        _lib.check(rc, self.ctx, "onmf_gather_columns")
+        return Xb
+
+    def code_accumulate(self, code, idx, H):
+        r, n = code.shape
+        if idx is None:
+            b, ip = n, C.c_void_p(0)
+        else:
+            idx = self.dev(idx, self.torch.int64)
+            b, ip = idx.numel(), _ptr(idx)
+        rc = self.lib.onmf_code_accumulate(self.ctx, r, n, _ptr(code), ip, b, _ptr(H), self.stream())
+        _lib.check(rc, self.ctx, "onmf_code_accumulate")
+        return code
+
+    def unfold3(self, T, mode, transpose=False):
+        n0, n1, n2 = T.shape
+        nm = T.shape[mode]
+        rest = T.numel() // nm
+        out = self.empty(rest, nm) if transpose else self.empty(nm, rest)
+        rc = self.lib.onmf_unfold3(self.ctx, n0, n1, n2, _ptr(T), int(mode), int(bool(transpose)),
+                                   _ptr(out), self.stream())
+        _lib.check(rc, self.ctx, "onmf_unfold3")
+        return out
+
+    def rand(self, rows, cols, seed=None):
+        out = self.empty(rows, cols)
+        if seed is None:
+            seed = self.next_seed()
+        rc = self.lib.onmf_fill_uniform(self.ctx, _ptr(out), out.numel(), C.c_uint64(seed),
+                                        self.stream())
+        _lib.check(rc, self.ctx, "onmf_fill_uniform")
+        return out

@@ -1,0 +1,151 @@
+"""Drop-in for the reference's ``src/ontf.py``: ``Online_NTF`` (src/ontf.py:19-244).
+
+The tensor is unfolded along ``mode`` (optionally transposed: ``learn_joint_dict``), then the same
+online step runs as in ``onmf``; unlike ``Online_NMF.train_dict`` the aggregates ARE carried between
+the steps of one call (src/ontf.py:236).  The code matrix of this class is (b x r), the transpose of
+onmf's (src/ontf.py:86, :147-148).
+
+The reference hands the sparse-code solve to scikit-learn (``SparseCoder``, lasso_lars, positive
+codes, alpha = ``self.alpha`` or 2; src/ontf.py:79-86).  Here the same convex problem
+    min_{h >= 0}  0.5 * ||x - W h||^2 + alpha * ||h||_1        (per column)
+is solved on the GPU by exact cyclic coordinate descent from h = 0, run until the relative change
+of the code per sweep falls under ``cd_tol`` (at most ``cd_max_sweeps`` sweeps).  It reaches the
+optimum that LARS approximates; it does not retrace the LARS path.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _lib
+from .engine import get_engine
+from .onmf import _is_torch, _out, _weight
+
+__all__ = ["Online_NTF"]
+
+DEBUG = False
+
+
+class Online_NTF():
+
+    def __init__(self,
+                 X, n_components=100,
+                 iterations=500,
+                 sub_iterations=10,
+                 batch_size=20,
+                 ini_dict=None,
+                 ini_A=None,
+                 ini_B=None,
+                 history=0,
+                 mode=0,
+                 learn_joint_dict=False,
+                 alpha=None,
+                 beta=None,
+                 subsample=True,
+                 *,
+                 rng="numpy",
+                 seed=0,
+                 device=None,
+                 cd_tol=1e-6,
+                 cd_max_sweeps=4000):
+        self.X = X
+        self.n_components = n_components
+        self.batch_size = batch_size
+        self.iterations = iterations
+        self.sub_iterations = sub_iterations
+        self.initial_dict = ini_dict
+        self.initial_A = ini_A
+        self.initial_B = ini_B
+        self.history = history
+        self.alpha = alpha
+        self.beta = beta
+        self.mode = mode
+        self.learn_joint_dict = learn_joint_dict
+        self.code = np.zeros(shape=(X.shape[1], n_components))
+        self.subsample = subsample
+        self.rng = rng
+        self.seed = seed
+        self._device = device
+        self._torch_io = _is_torch(X)
+        self.cd_tol = cd_tol
+        self.cd_max_sweeps = cd_max_sweeps
+        self.last_sweeps = None
+
+    def _engine(self):
+        return get_engine(self._device)
+
+    def _code_dev(self, eng, Xd, Wd):
+        """Device solve; returns H as (r x b)."""
+        a = 2 if self.alpha is None else self.alpha          # src/ontf.py:79-84
+        H0 = eng.zeros(Wd.shape[1], Xd.shape[1])
+        H, sweeps, _ = eng.sparse_code(Xd, Wd, H0=H0, alpha=a, sub_iter=self.cd_max_sweeps,
+                                       stopping_diff=self.cd_tol, mode=_lib.CODER_EXACT_CD)
+        self.last_sweeps = sweeps
+        return H
+
+    def joint_sparse_code_tensor(self, X, W):
+        """Code H (samples x topics) with W H^T ~ X (src/ontf.py:59-89)."""
+        eng = self._engine()
+        H = self._code_dev(eng, eng.dev(X), eng.dev(W))
+        return _out(H.t().contiguous(), _is_torch(X))
+
+    def update_dict(self, W, A, B):
+        """Same block-coordinate pass as onmf (src/ontf.py:91-115)."""
+        eng = self._engine()
+        return _out(eng.update_dict(eng.dev(W), eng.dev(A), eng.dev(B)), _is_torch(W))
+
+    def _step_dev(self, eng, Xd, Ad, Bd, Wd, t):
+        H = self._code_dev(eng, Xd, Wd)
+        w = _weight(t, self.beta)
+        A1, B1, _ = eng.aggregate(Xd, H, w, Ad, Bd)          # src/ontf.py:147-148
+        W1 = eng.update_dict(Wd, Ad, Bd)                      # old aggregates, src/ontf.py:151
+        self.history = np.float64(t) + 1
+        return H, A1, B1, W1
+
+    def step(self, X, A, B, W, t):
+        """One iteration (src/ontf.py:117-154): returns H1 (b x r), A1, B1, W1."""
+        eng = self._engine()
+        lt = _is_torch(X)
+        H, A1, B1, W1 = self._step_dev(eng, eng.dev(X), eng.dev(A), eng.dev(B), eng.dev(W), t)
+        return _out(H.t().contiguous(), lt), _out(A1, lt), _out(B1, lt), _out(W1, lt)
+
+    def unfold(self):
+        """tl_unfold(X, mode), transposed when learn_joint_dict (src/ontf.py:203-208); device tensor."""
+        eng = self._engine()
+        T = eng.dev(self.X)
+        if T.dim() != 3:
+            raise ValueError("Online_NTF expects a 3-way tensor, got shape %s" % (tuple(T.shape),))
+        return eng.unfold3(T, self.mode, transpose=bool(self.learn_joint_dict))
+
+    def train_dict_single(self):
+        """Learn W along one mode (src/ontf.py:156-244): returns W, A, B, code."""
+        eng = self._engine()
+        lt = self._torch_io
+        Xu = self.unfold()
+        d, n = Xu.shape
+        r = self.n_components
+        if self.initial_dict is None:
+            if self.rng == "numpy":
+                Wd = eng.dev(np.random.rand(d, r))           # src/ontf.py:213
+            else:
+                Wd = eng.rand(d, r, eng.next_seed(self.seed))
+            if DEBUG:
+                print('W.shape', tuple(Wd.shape))
+            Ad, Bd = eng.zeros(r, r), eng.zeros(r, d)
+            ran = True
+        else:
+            Wd, Ad, Bd = eng.dev(self.initial_dict), eng.dev(self.initial_A), eng.dev(self.initial_B)
+            ran = False
+        t0 = self.history
+        for i in np.arange(1, self.iterations):
+            Xb = Xu
+            if self.subsample:
+                if self.rng == "numpy":
+                    idx = np.random.randint(n, size=self.batch_size)   # src/ontf.py:230
+                else:
+                    idx = eng.torch.randint(n, (self.batch_size,), device=eng.device)
+                Xb = eng.gather_columns(Xu, idx)
+            _, Ad, Bd, Wd = self._step_dev(eng, Xb, Ad, Bd, Wd, t0 + i)
+            ran = True
+        if not ran:
+            return self.initial_dict, self.initial_A, self.initial_B, self.code
+        return _out(Wd, lt), _out(Ad, lt), _out(Bd, lt), self.code
