@@ -51,11 +51,226 @@ __global__ __launch_bounds__(64) void sweep_column_kernel(int r, int b, const fl
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Tile kernel: blocked Gauss-Seidel on the matrix cores.
+//
+// A wave owns 16 columns of H.  Rows are cut into NB blocks of 16.  For block K the products
+//     R = Gm[K, :] . H          (16 x r times r x 16, v_mfma_f32_16x16x4_f32, exact fp32)
+// use the current H (blocks < K already updated this sweep), then the 16 rows of the block are
+// updated in order on the VALU with the in-block corrections  Gm[k, j] * (h_j_new - h_j_old), j < k.
+//
+// Register layout = the MFMA's own: lane l holds column (l & 15); lane group g = l >> 4 holds rows
+// 16J + 4g + t (t = 0..3) of every block J, both for H (the B operand, k index = g) and for the
+// accumulator R (row 4g + t).  H and Cm stay in registers for the whole sweep.
+//
+// LDS holds Gm as 16x16 blocks (1 KB each), XOR-swizzled so that the A-operand read of block (K,J)
+// - one ds_read_b128 per lane: row (l & 15), columns 4g..4g+3 - is conflict-free.  When all NB*NB
+// blocks do not fit (r = 256), only blocks J <= K are stored and block (K,J), J > K, is read
+// transposed from block (J,K) (Gm is symmetric).  A second set of NB blocks holds the strictly
+// lower triangles of the diagonal blocks for the in-block corrections.
+//
+// In-block update, per quad Q of 4 consecutive rows (they live in lane group Q): the owner group
+// runs its 4 rows in order; the 4 deltas are then broadcast to the other groups (ds_bpermute) and
+// pushed into the accumulators of the rows that come later in the block.
+// ---------------------------------------------------------------------------------------------
+constexpr int TILE_WAVES = 8;
+
+__device__ __forceinline__ int swz(int row) { return (-(row >> 2)) & 3; }   // column-quad XOR per row
+
+// dword offset of element (i, j) inside one swizzled 16x16 block
+__device__ __forceinline__ int blk_off(int i, int j) { return i * 16 + 4 * ((j >> 2) ^ swz(i)) + (j & 3); }
+
+template <int NB, bool HALF>
+__device__ __forceinline__ int blk_index(int K, int J) {
+    return HALF ? (K * (K + 1) / 2 + J) : (K * NB + J);
+}
+
+template <int NB, bool HALF>
+__global__ __launch_bounds__(TILE_WAVES * 64, 2) void sweep_tile_kernel(
+    int r, int b, const float* __restrict__ Gm, const float* __restrict__ Cm,
+    const float* __restrict__ Hin, float* __restrict__ Hout, float alpha, float rdamp, int exact_cd,
+    double* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NBLK = HALF ? NB * (NB + 1) / 2 : NB * NB;
+    float* Gs = lds;                       // NBLK blocks
+    float* Ls = lds + NBLK * 256;          // NB blocks: strictly-lower part of the diagonal blocks
+    float* steps = Ls + NB * 256;          // 16*NB step sizes (0 for padded rows)
+
+    // ---- stage Gm into LDS (whole workgroup) ----
+    const int tid = threadIdx.x;
+    for (int K = 0; K < NB; ++K) {
+        const int jend = HALF ? (K + 1) : NB;
+        for (int e = tid; e < jend * 256; e += TILE_WAVES * 64) {
+            const int J = e >> 8, i = (e >> 4) & 15, j = e & 15;
+            const int row = 16 * K + i, col = 16 * J + j;
+            const float v = (row < r && col < r) ? Gm[(size_t)row * r + col] : 0.f;
+            Gs[blk_index<NB, HALF>(K, J) * 256 + blk_off(i, j)] = v;
+            if (J == K) Ls[K * 256 + blk_off(i, j)] = (j < i) ? v : 0.f;
+        }
+    }
+    for (int k = tid; k < 16 * NB; k += TILE_WAVES * 64) {
+        float st = 0.f;
+        if (k < r) {
+            const float gkk = Gm[(size_t)k * r + k];
+            st = exact_cd ? (gkk > 0.f ? 1.0f / gkk : 0.f) : rdamp / (gkk + 1.0f);
+        }
+        steps[k] = st;
+    }
+    __syncthreads();
+
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int c = lane & 15;
+    const int g = lane >> 4;
+    const int col = (blockIdx.x * TILE_WAVES + wave) * 16 + c;
+    const bool cvalid = col < b;
+    const int sw_c = swz(c);               // swizzle of row c (c doubles as the A-operand row index)
+
+    // H and Cm go through buffer descriptors: byte address = (per-lane voffset) + (wave-uniform
+    // soffset = row offset * b), no per-access address registers, and the hardware range check
+    // returns 0 for rows >= r (their offset is past r*b floats) and drops such stores.  Columns
+    // >= b are clamped for loads (value masked) and pushed out of range for stores.
+    // The host guarantees r * b * 4 < 2^31.
+    const unsigned nbytes = (unsigned)r * (unsigned)b * 4u;
+    const auto rs_h = __builtin_amdgcn_make_buffer_rsrc((void*)Hin, 0, nbytes, 0x00020000);
+    const auto rs_c = __builtin_amdgcn_make_buffer_rsrc((void*)Cm, 0, nbytes, 0x00020000);
+    const auto rs_o = __builtin_amdgcn_make_buffer_rsrc((void*)Hout, 0, nbytes, 0x00020000);
+    const int voff = (4 * g * b + min(col, b - 1)) * 4;
+    const int voff_st = cvalid ? voff : (int)0x80000000;
+    float h[NB][4];
+    float hsum = 0.f, dsum = 0.f;
+#pragma unroll
+    for (int J = 0; J < NB; ++J) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_h, voff, (16 * J + t) * b * 4, 0));
+            v = cvalid ? v : 0.f;
+            h[J][t] = v;
+            hsum = fmaf(v, v, hsum);
+        }
+    }
+
+#pragma unroll
+    for (int K = 0; K < NB; ++K) {
+        // keep the compiler from hoisting later blocks' LDS reads above this point (register budget)
+        __builtin_amdgcn_sched_barrier(0);
+        // Cm is touched once per sweep: fetch this block's four values now, use them after the MFMAs
+        float cmk[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            cmk[t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_c, voff, (16 * K + t) * b * 4, 0));
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int J = 0; J < NB; ++J) {
+            float a0, a1, a2, a3;
+            if (!HALF || J <= K) {
+                const float4 a = *reinterpret_cast<const float4*>(
+                    Gs + blk_index<NB, HALF>(K, J) * 256 + c * 16 + 4 * (g ^ sw_c));
+                a0 = a.x; a1 = a.y; a2 = a.z; a3 = a.w;
+            } else {
+                // Gm[16K+c][16J+4g+t] = Gm[16J+4g+t][16K+c]: rows 4g+t of block (J,K), column c
+                const float* blk = Gs + blk_index<NB, HALF>(J, K) * 256 + 64 * g +
+                                   4 * ((c >> 2) ^ ((-g) & 3)) + (c & 3);
+                a0 = blk[0]; a1 = blk[16]; a2 = blk[32]; a3 = blk[48];
+            }
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, h[J][0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, h[J][1], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, h[J][2], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, h[J][3], acc1, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        float acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = acc0[t] + acc1[t];
+        const float4 st4 = *reinterpret_cast<const float4*>(steps + 16 * K + 4 * g);
+        // columns past b hold zeros and must stay zero (their stores are dropped, but their
+        // deltas would pollute the statistics): step 0
+        const float st[4] = {cvalid ? st4.x : 0.f, cvalid ? st4.y : 0.f, cvalid ? st4.z : 0.f,
+                             cvalid ? st4.w : 0.f};
+
+#pragma unroll
+        for (int Q = 0; Q < 4; ++Q) {
+            const bool own = (g == Q);
+            // Lq[t][tj] = strictly-lower Gm[16K+4g+t][16K+4Q+tj]
+            float Lq[4][4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float4 v = *reinterpret_cast<const float4*>(
+                    Ls + K * 256 + (4 * g + t) * 16 + 4 * (Q ^ ((-g) & 3)));
+                Lq[t][0] = v.x; Lq[t][1] = v.y; Lq[t][2] = v.z; Lq[t][3] = v.w;
+            }
+            float dq[4];
+#pragma unroll
+            for (int tj = 0; tj < 4; ++tj) {
+                const float hold = h[K][tj];
+                const float grad = acc[tj] - cmk[tj] + alpha;
+                const float hnew = fmaxf(hold - grad * st[tj], 0.f);
+                const float dl = own ? (hnew - hold) : 0.f;
+                h[K][tj] = own ? hnew : hold;
+                dsum = fmaf(dl, dl, dsum);
+                dq[tj] = dl;
+#pragma unroll
+                for (int t = tj + 1; t < 4; ++t) acc[t] = fmaf(Lq[t][tj], dl, acc[t]);
+            }
+            if (Q < 3) {
+#pragma unroll
+                for (int tj = 0; tj < 4; ++tj) {
+                    const float all = __shfl(dq[tj], 16 * Q + c, 64);
+                    const float other = own ? 0.f : all;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[t] = fmaf(Lq[t][tj], other, acc[t]);
+                }
+            }
+            asm volatile("" : "+v"(dsum));     // keep the running sum current (no deferred chain)
+        }
+    }
+
+#pragma unroll
+    for (int J = 0; J < NB; ++J) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(h[J][t]), rs_o, voff_st,
+                                                  (16 * J + t) * b * 4, 0);
+    }
+    double ds = dsum, hh = hsum;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        ds += __shfl_xor(ds, off);
+        hh += __shfl_xor(hh, off);
+    }
+    if (lane == 0) {
+        const int slot = blockIdx.x * TILE_WAVES + wave;
+        stats[2 * slot + 0] = ds;
+        stats[2 * slot + 1] = hh;
+    }
+}
+
+template <int NB, bool HALF>
+int run_tile(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm, const float* Hin, float* Hout,
+             float alpha, float damp, int exact_cd, double* stats, int* n_groups, hipStream_t s) {
+    constexpr int NBLK = HALF ? NB * (NB + 1) / 2 : NB * NB;
+    constexpr size_t lds = sizeof(float) * ((size_t)NBLK * 256 + NB * 256 + NB * 16);
+    static_assert(lds <= 160 * 1024, "Gm blocks do not fit the LDS");
+    static bool attr_done = false;
+    if (!attr_done) {
+        HIP_TRY(c, hipFuncSetAttribute((const void*)sweep_tile_kernel<NB, HALF>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    const int cols_per_wg = TILE_WAVES * 16;
+    const int wgs = (b + cols_per_wg - 1) / cols_per_wg;
+    *n_groups = wgs * TILE_WAVES;
+    hipLaunchKernelGGL((sweep_tile_kernel<NB, HALF>), dim3(wgs), dim3(TILE_WAVES * 64), lds, s, r, b, Gm,
+                       Cm, Hin, Hout, alpha, 1.0f / damp, exact_cd, stats);
+    HIP_TRY(c, hipGetLastError());
+    return ONMF_OK;
+}
+
 }  // namespace
 
-int launch_sweep(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm, const float* Hin,
-                 float* Hout, float alpha, float damp, int exact_cd, double* stats, int* n_groups,
-                 hipStream_t s) {
+static int launch_sweep_column(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm,
+                               const float* Hin, float* Hout, float alpha, float damp, int exact_cd,
+                               double* stats, int* n_groups, hipStream_t s) {
     const size_t lds = (size_t)r * 64 * sizeof(float);
     if (lds > 160 * 1024) return onmf_fail(c, ONMF_ERR_ARG, "sweep: r=%d needs %zu B of LDS", r, lds);
     static size_t attr_bytes = 0;
@@ -70,4 +285,39 @@ int launch_sweep(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm, co
                        alpha, damp, exact_cd, stats);
     HIP_TRY(c, hipGetLastError());
     return ONMF_OK;
+}
+
+int launch_sweep(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm, const float* Hin,
+                 float* Hout, float alpha, float damp, int exact_cd, double* stats, int* n_groups,
+                 hipStream_t s) {
+    const int nb = (r + 15) / 16;
+    const bool fits_i32 = (double)r * (double)b * 4.0 < 2147483000.0;
+    const bool want_tile = fits_i32 && ((c->sweep_kernel == 2) || (c->sweep_kernel == 0 && nb <= 16));
+    if (!want_tile || nb > 16) {
+        if (c->sweep_kernel == 2)
+            return onmf_fail(c, ONMF_ERR_ARG, "sweep: the tile kernel covers r <= 256 (r=%d)", r);
+        return launch_sweep_column(c, r, b, Gm, Cm, Hin, Hout, alpha, damp, exact_cd, stats, n_groups, s);
+    }
+#define TILE_CASE(NBV, HALFV) \
+    case NBV: return run_tile<NBV, HALFV>(c, r, b, Gm, Cm, Hin, Hout, alpha, damp, exact_cd, stats, n_groups, s)
+    switch (nb) {
+        TILE_CASE(1, false);
+        TILE_CASE(2, false);
+        TILE_CASE(3, false);
+        TILE_CASE(4, false);
+        TILE_CASE(5, false);
+        TILE_CASE(6, false);
+        TILE_CASE(7, false);
+        TILE_CASE(8, false);
+        TILE_CASE(9, false);
+        TILE_CASE(10, false);
+        TILE_CASE(11, false);
+        TILE_CASE(12, true);
+        TILE_CASE(13, true);
+        TILE_CASE(14, true);
+        TILE_CASE(15, true);
+        TILE_CASE(16, true);
+    }
+#undef TILE_CASE
+    return onmf_fail(c, ONMF_ERR_ARG, "sweep: unsupported r=%d", r);
 }
