@@ -241,7 +241,7 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
     ONMF_TRY(onmf_reserve(c, c->cm, rb * sizeof(float), "Cm"));
     ONMF_TRY(onmf_reserve(c, c->hbuf[0], rb * sizeof(float), "code buffer"));
     ONMF_TRY(onmf_reserve(c, c->hbuf[1], rb * sizeof(float), "code buffer"));
-    const int max_groups = (b + 15) / 16 + 8;
+    const int max_groups = (b + 15) / 16 + 64;
     ONMF_TRY(onmf_reserve(c, c->stats, (size_t)max_groups * 2 * sizeof(double), "sweep statistics"));
     ONMF_TRY(onmf_reserve_pinned(c, std::max((size_t)max_groups * 2 * sizeof(double),
                                              (size_t)2 * r * r * sizeof(float))));

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(64) void sweep_column_kernel(int r, int b, const fl
 // runs its 4 rows in order; the 4 deltas are then broadcast to the other groups (ds_bpermute) and
 // pushed into the accumulators of the rows that come later in the block.
 // ---------------------------------------------------------------------------------------------
-constexpr int TILE_WAVES = 8;
+constexpr int TILE_WAVES = 16;
 
 __device__ __forceinline__ int swz(int row) { return (-(row >> 2)) & 3; }   // column-quad XOR per row
 
@@ -86,7 +86,7 @@ __device__ __forceinline__ int blk_index(int K, int J) {
 }
 
 template <int NB, bool HALF>
-__global__ __launch_bounds__(TILE_WAVES * 64, 2) void sweep_tile_kernel(
+__global__ __launch_bounds__(TILE_WAVES * 64) void sweep_tile_kernel(
     int r, int b, const float* __restrict__ Gm, const float* __restrict__ Cm,
     const float* __restrict__ Hin, float* __restrict__ Hout, float alpha, float rdamp, int exact_cd,
     double* __restrict__ stats) {
