@@ -127,10 +127,13 @@ double onmf_host_lambda_max(const float* S_host, int n);
  *                          matrices + eigenvalues) instead of deciding by norm bounds when those
  *                          are conclusive; dist_trace then holds every dist value.
  *   ONMF_OPT_SWEEP_KERNEL  0 = pick by shape, 1 = column-per-lane kernel, 2 = MFMA tile kernel.
+ *   ONMF_OPT_OVERLAP_DICT  != 0 (default): onmf_step runs the dictionary pass on a second stream
+ *                          beside the code solve when no output aliases an input.
  */
 #define ONMF_OPT_PROFILE 1
 #define ONMF_OPT_EXACT_STOP 2
 #define ONMF_OPT_SWEEP_KERNEL 3
+#define ONMF_OPT_OVERLAP_DICT 4
 int onmf_set_option(onmf_ctx* ctx, int key, int value);
 /* Summed device time (ms) and number of sweep-kernel launches since the previous call. */
 int onmf_get_profile(onmf_ctx* ctx, double* sweep_ms, int* sweep_launches);

@@ -175,11 +175,14 @@ int onmf_destroy(onmf_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     DevBuf* bufs[] = {&c->slab, &c->cm, &c->gram, &c->hbuf[0], &c->hbuf[1], &c->stats, &c->small,
-                      &c->qt, &c->sync, &c->idx, &c->dbuf};
+                      &c->qt, &c->sync, &c->idx, &c->dbuf, &c->slab_side};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (c->pinned) (void)hipHostFree(c->pinned);
     for (hipEvent_t ev : c->ev) (void)hipEventDestroy(ev);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->side) (void)hipStreamDestroy(c->side);
     delete c;
     return ONMF_OK;
 }
@@ -192,6 +195,7 @@ int onmf_set_option(onmf_ctx* c, int key, int value) {
         case ONMF_OPT_PROFILE: c->profile = value; return ONMF_OK;
         case ONMF_OPT_EXACT_STOP: c->exact_stop = value; return ONMF_OK;
         case ONMF_OPT_SWEEP_KERNEL: c->sweep_kernel = value; return ONMF_OK;
+        case ONMF_OPT_OVERLAP_DICT: c->overlap_dict = value; return ONMF_OK;
         default: return onmf_fail(c, ONMF_ERR_ARG, "onmf_set_option: unknown key %d", key);
     }
 }
@@ -414,8 +418,35 @@ int onmf_step(onmf_ctx* c, int d, int r, int b, const float* X, int ldx, const f
         ONMF_TRY(onmf_reserve(c, c->dbuf, (size_t)r * b * sizeof(float) * 2, "step code"));
         H = (float*)c->dbuf.p + (size_t)r * b;
     }
-    // order keeps every in-place aliasing legal: code (reads W_in) -> dictionary pass with the OLD
-    // aggregates (src/onmf.py:161) -> aggregates
+    const bool aliased = (W_out == W_in) || (A_out == A_in) || (B_out == B_in);
+    if (c->overlap_dict && !aliased) {
+        // The dictionary pass reads only W_in and the OLD aggregates (src/onmf.py:161), so it is
+        // independent of this step's code and runs on a second stream (default priority) beside it.
+        if (!c->side) {
+            HIP_TRY(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+            HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+            HIP_TRY(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+        }
+        HIP_TRY(c, hipEventRecord(c->ev_fork, s));
+        HIP_TRY(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
+        int rc = launch_dict_pass(c, d, r, W_in, A_in, B_in, W_out, c->side);
+        hipError_t e1 = hipEventRecord(c->ev_join, c->side);
+        int rc2 = ONMF_OK;
+        if (rc == ONMF_OK)
+            rc2 = sparse_code_impl(c, d, r, b, X, ldx, W_in, H0, seed, alpha, sub_iter, stopping_diff,
+                                   ONMF_CODER_DAMPED, H, sweeps_done, dist_trace, s);
+        if (rc == ONMF_OK && rc2 == ONMF_OK)
+            rc2 = aggregate_impl(c, d, r, b, X, ldx, H, w, A_in, B_in, C_in, A_out, B_out, C_out, s);
+        // always rejoin, also on an error path, so the side stream never outlives the call's buffers
+        hipError_t e2 = hipStreamWaitEvent(s, c->ev_join, 0);
+        if (rc != ONMF_OK) return rc;
+        if (rc2 != ONMF_OK) return rc2;
+        HIP_TRY(c, e1);
+        HIP_TRY(c, e2);
+        return dict_check(c, r, d, s);
+    }
+    // serial order keeps every in-place aliasing legal: code (reads W_in) -> dictionary pass with
+    // the OLD aggregates -> aggregates
     ONMF_TRY(sparse_code_impl(c, d, r, b, X, ldx, W_in, H0, seed, alpha, sub_iter, stopping_diff,
                               ONMF_CODER_DAMPED, H, sweeps_done, dist_trace, s));
     ONMF_TRY(launch_dict_pass(c, d, r, W_in, A_in, B_in, W_out, s));

@@ -44,6 +44,10 @@ struct onmf_ctx {
     std::vector<hipEvent_t> ev;     // pairs of events bracketing sweep launches
     int ev_used = 0;
     DevBuf dbuf;                    // H - H_prev for the exact stopping test (r x b)
+    DevBuf slab_side;               // split-K slabs of products issued on the side stream
+    hipStream_t side = nullptr;     // dictionary pass runs here, beside the code solve
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int overlap_dict = 1;
 };
 
 int onmf_fail(onmf_ctx* c, int code, const char* fmt, ...);
@@ -71,7 +75,7 @@ int onmf_reserve_pinned(onmf_ctx* c, size_t bytes);
 // b_kn: B(k,n)=B[k*ldb+n] else B[n*ldb+k].  Cin may be null when beta == 0; Cin may alias C.
 int launch_gemm(onmf_ctx* c, bool a_km, bool b_kn, int M, int N, int K, const float* A, int lda,
                 const float* B, int ldb, float alpha, float beta, const float* Cin, float* C,
-                int ldc, hipStream_t s);
+                int ldc, hipStream_t s, DevBuf* slab = nullptr);
 
 // One Gauss-Seidel sweep over all rows: Hout = sweep(Hin).  stats (device, 2 doubles per
 // workgroup) receives sum((Hout-Hin)^2) and sum(Hin^2) partials; *n_groups = number of pairs.

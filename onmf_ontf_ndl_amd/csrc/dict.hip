@@ -105,7 +105,7 @@ int launch_dict_pass(onmf_ctx* c, int d, int r, const float* Win, const float* A
     ONMF_TRY(onmf_reserve(c, c->qt, (size_t)r * d * sizeof(float), "dictionary Qt"));
     float* Qt = (float*)c->qt.p;
     ONMF_TRY(launch_gemm(c, /*a_km=*/true, /*b_kn=*/false, r, d, r, A, r, Win, r, 1.f, 0.f, nullptr,
-                         Qt, d, s));
+                         Qt, d, s, &c->slab_side));
     const size_t ngran = (size_t)r * nwg;
     ONMF_TRY(onmf_reserve(c, c->sync, ngran * sizeof(u64) + 64, "dictionary sync words"));
     u64* gran = (u64*)c->sync.p;

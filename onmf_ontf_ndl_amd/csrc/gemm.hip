@@ -233,7 +233,8 @@ int run(onmf_ctx* c, const GemmParams& p, dim3 grid, hipStream_t s) {
 
 int launch_gemm(onmf_ctx* c, bool a_km, bool b_kn, int M, int N, int K, const float* A, int lda,
                 const float* B, int ldb, float alpha, float beta, const float* Cin, float* C,
-                int ldc, hipStream_t s) {
+                int ldc, hipStream_t s, DevBuf* slab) {
+    if (!slab) slab = &c->slab;
     if (M <= 0 || N <= 0 || K < 0) return onmf_fail(c, ONMF_ERR_ARG, "gemm: bad shape %dx%dx%d", M, N, K);
     if (beta != 0.f && Cin == nullptr) return onmf_fail(c, ONMF_ERR_ARG, "gemm: beta without Cin");
     GemmParams p;
@@ -260,8 +261,8 @@ int launch_gemm(onmf_ctx* c, bool a_km, bool b_kn, int M, int N, int K, const fl
     p.k_per_split = kt_per * BK;
     p.splits = splits;
     if (splits > 1) {
-        ONMF_TRY(onmf_reserve(c, c->slab, (size_t)splits * M * N * sizeof(float), "split-K slabs"));
-        p.slab = (float*)c->slab.p;
+        ONMF_TRY(onmf_reserve(c, *slab, (size_t)splits * M * N * sizeof(float), "split-K slabs"));
+        p.slab = (float*)slab->p;
     }
     dim3 grid(tiles, 1, splits);
     int rc;
