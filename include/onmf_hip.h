@@ -56,8 +56,10 @@ const char* onmf_last_error(onmf_ctx* ctx);
  *               that needs that exact stream draws it itself and passes H0).
  *   stopping_diff: the loop ends when sigma_max(H - H_prev)/sigma_max(H_prev) <= stopping_diff
  *               (spectral norms, onmf.py:265) or after sub_iter sweeps.
- *   sweeps_done (host int*, nullable), dist_trace (host float[sub_iter], nullable; entries for
- *               sweeps whose test was decided by bounds alone are set to NaN).
+ *   sweeps_done (host int*, nullable), dist_trace (host float[sub_iter], nullable): dist per
+ *               sweep where the test was evaluated in full; where rigorous bounds decided it, the
+ *               deciding bound (a lower bound of dist if the loop went on, an upper bound if it
+ *               stopped); NaN for sweeps that did not run.
  *   The radius argument r of the reference is not supported: every caller passes r=None.
  */
 int onmf_sparse_code(onmf_ctx* ctx, int d, int r, int b, const float* X, int ldx, const float* W,
@@ -129,11 +131,16 @@ double onmf_host_lambda_max(const float* S_host, int n);
  *   ONMF_OPT_SWEEP_KERNEL  0 = pick by shape, 1 = column-per-lane kernel, 2 = MFMA tile kernel.
  *   ONMF_OPT_OVERLAP_DICT  != 0 (default): onmf_step runs the dictionary pass on a second stream
  *                          beside the code solve when no output aliases an input.
+ *   ONMF_OPT_SCREEN_STOP   != 0 (default): decide the stopping test on the device from rigorous
+ *                          bounds that the sweep kernel produces as by-products, all sweeps
+ *                          enqueued without host round trips; the full test runs only where the
+ *                          bounds straddle stopping_diff.  0: one host decision per sweep.
  */
 #define ONMF_OPT_PROFILE 1
 #define ONMF_OPT_EXACT_STOP 2
 #define ONMF_OPT_SWEEP_KERNEL 3
 #define ONMF_OPT_OVERLAP_DICT 4
+#define ONMF_OPT_SCREEN_STOP 5
 int onmf_set_option(onmf_ctx* ctx, int key, int value);
 /* Summed device time (ms) and number of sweep-kernel launches since the previous call. */
 int onmf_get_profile(onmf_ctx* ctx, double* sweep_ms, int* sweep_launches);

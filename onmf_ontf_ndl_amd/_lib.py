@@ -19,6 +19,7 @@ OPT_PROFILE = 1
 OPT_EXACT_STOP = 2
 OPT_SWEEP_KERNEL = 3
 OPT_OVERLAP_DICT = 4
+OPT_SCREEN_STOP = 5
 
 _f = C.c_void_p          # device float*
 _ctx = C.c_void_p

@@ -175,7 +175,7 @@ int onmf_destroy(onmf_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     DevBuf* bufs[] = {&c->slab, &c->cm, &c->gram, &c->hbuf[0], &c->hbuf[1], &c->stats, &c->small,
-                      &c->qt, &c->sync, &c->idx, &c->dbuf, &c->slab_side};
+                      &c->qt, &c->sync, &c->idx, &c->dbuf, &c->slab_side, &c->screen};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (c->pinned) (void)hipHostFree(c->pinned);
@@ -196,6 +196,7 @@ int onmf_set_option(onmf_ctx* c, int key, int value) {
         case ONMF_OPT_EXACT_STOP: c->exact_stop = value; return ONMF_OK;
         case ONMF_OPT_SWEEP_KERNEL: c->sweep_kernel = value; return ONMF_OK;
         case ONMF_OPT_OVERLAP_DICT: c->overlap_dict = value; return ONMF_OK;
+        case ONMF_OPT_SCREEN_STOP: c->screen_stop = value; return ONMF_OK;
         default: return onmf_fail(c, ONMF_ERR_ARG, "onmf_set_option: unknown key %d", key);
     }
 }
@@ -233,6 +234,29 @@ static int profile_mark(onmf_ctx* c, hipStream_t s) {
 // point (src/onmf.py:252, :265): NaN (0/0) ends the loop, +inf (x/0) continues it.
 static bool keep_sweeping(double dist, double tol) { return dist > tol; }
 
+// Full stopping test of one sweep: dist = sigma_max(Hnew - Hold) / sigma_max(Hold) through the two
+// r x r Gram matrices (MFMA products) and their top eigenvalues (host, double).  Synchronises s.
+static int exact_dist(onmf_ctx* c, int r, int b, const float* Hnew, const float* Hold, hipStream_t s,
+                      double* dist) {
+    const size_t rb = (size_t)r * b;
+    ONMF_TRY(onmf_reserve(c, c->dbuf, rb * sizeof(float), "code difference"));
+    ONMF_TRY(onmf_reserve(c, c->small, (size_t)2 * r * r * sizeof(float), "stop-test Grams"));
+    ONMF_TRY(onmf_reserve_pinned(c, (size_t)2 * r * r * sizeof(float)));
+    float* D = (float*)c->dbuf.p;
+    float* G1 = (float*)c->small.p;
+    float* G0 = G1 + (size_t)r * r;
+    ONMF_TRY(launch_sub(D, Hnew, Hold, rb, s));
+    ONMF_TRY(launch_gemm(c, false, false, r, r, b, D, b, D, b, 1.f, 0.f, nullptr, G1, r, s));
+    ONMF_TRY(launch_gemm(c, false, false, r, r, b, Hold, b, Hold, b, 1.f, 0.f, nullptr, G0, r, s));
+    HIP_TRY(c, hipMemcpyAsync(c->pinned, G1, (size_t)2 * r * r * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    const float* hg = (const float*)c->pinned;
+    const double l1 = host_lambda_max(hg, r);
+    const double l0 = host_lambda_max(hg + (size_t)r * r, r);
+    *dist = std::sqrt(std::max(l1, 0.0)) / std::sqrt(std::max(l0, 0.0));
+    return ONMF_OK;
+}
+
 static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, int ldx,
                             const float* W, const float* H0, uint64_t seed, float alpha,
                             int sub_iter, float stopping_diff, int coder_mode, float* H,
@@ -248,94 +272,136 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
     const int max_groups = (b + 15) / 16 + 64;
     ONMF_TRY(onmf_reserve(c, c->stats, (size_t)max_groups * 2 * sizeof(double), "sweep statistics"));
     ONMF_TRY(onmf_reserve_pinned(c, std::max((size_t)max_groups * 2 * sizeof(double),
-                                             (size_t)2 * r * r * sizeof(float))));
+                                             (size_t)ScreenLayout::TOTAL * sizeof(float))));
     float* Gm = (float*)c->gram.p;
     float* Cm = (float*)c->cm.p;
     // Gm = W^T W,  Cm = W^T X   (src/onmf.py:242-243)
     ONMF_TRY(launch_gemm(c, true, true, r, r, d, W, r, W, r, 1.f, 0.f, nullptr, Gm, r, s));
     ONMF_TRY(launch_gemm(c, true, true, r, b, d, W, r, X, ldx, 1.f, 0.f, nullptr, Cm, b, s));
-    float* cur = (float*)c->hbuf[0].p;
-    float* nxt = (float*)c->hbuf[1].p;
+    float* buf[2] = {(float*)c->hbuf[0].p, (float*)c->hbuf[1].p};
     if (H0) {
-        HIP_TRY(c, hipMemcpyAsync(cur, H0, rb * sizeof(float), hipMemcpyDeviceToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(buf[0], H0, rb * sizeof(float), hipMemcpyDeviceToDevice, s));
     } else {
-        ONMF_TRY(launch_fill_uniform(cur, rb, seed, s));
+        ONMF_TRY(launch_fill_uniform(buf[0], rb, seed, s));
     }
     const double tol = (double)stopping_diff;
     const double rank_cap = (double)std::min(r, b);
-    int done = 0;
-    double dist = 1.0;      // src/onmf.py:251
-    while (done < sub_iter && keep_sweeping(dist, tol)) {
-        const float damp = (float)std::sqrt((double)done + 10.0);
-        int groups = 0;
-        ONMF_TRY(profile_mark(c, s));
-        ONMF_TRY(launch_sweep(c, r, b, Gm, Cm, cur, nxt, alpha, damp,
-                              coder_mode == ONMF_CODER_EXACT_CD, (double*)c->stats.p, &groups, s));
-        ONMF_TRY(profile_mark(c, s));
-        HIP_TRY(c, hipMemcpyAsync(c->pinned, c->stats.p, (size_t)groups * 2 * sizeof(double),
-                                  hipMemcpyDeviceToHost, s));
-        HIP_TRY(c, hipStreamSynchronize(s));
-        const double* hs = (const double*)c->pinned;
-        double dsum = 0.0, hsum = 0.0;
-        for (int g = 0; g < groups; ++g) {
-            dsum += hs[2 * g];
-            hsum += hs[2 * g + 1];
-        }
-        // Decide `dist > tol` from Frobenius norms when they settle it:
-        //   s1 in [fD / sqrt(rank), fD],  s0 in [fH / sqrt(rank), fH]   (fD, fH Frobenius norms)
-        bool decided = false;
-        double shown = std::numeric_limits<double>::quiet_NaN();
-        const double fD = std::sqrt(dsum), fH = std::sqrt(hsum);
-        if (coder_mode == ONMF_CODER_EXACT_CD) {
-            // fixed-point iteration of the convex problem: stop on the relative Frobenius change
-            dist = (hsum == 0.0) ? (dsum == 0.0 ? 0.0 : std::numeric_limits<double>::infinity())
-                                 : fD / fH;
-            decided = true;
-            shown = dist;
-        } else if (!c->exact_stop) {
-            if (hsum == 0.0) {                    // s0 == 0: dist is NaN (stop) or +inf (continue)
-                dist = (dsum == 0.0) ? std::numeric_limits<double>::quiet_NaN()
-                                     : std::numeric_limits<double>::infinity();
-                decided = true;
-                shown = dist;
-            } else if (dsum == 0.0) {
-                dist = 0.0;
-                decided = true;
-                shown = 0.0;
-            } else if (tol < 0.0) {
-                dist = 1.0;                       // any positive value compares the same way
-                decided = true;
-            } else {
-                const double lower = (fD / std::sqrt(rank_cap)) / fH * (1.0 - 1e-4);
-                const double upper = fD / (fH / std::sqrt(rank_cap)) * (1.0 + 1e-4);
-                if (lower > tol) { dist = lower; decided = true; }
-                else if (upper <= tol) { dist = upper; decided = true; }
+    const int exact_cd = (coder_mode == ONMF_CODER_EXACT_CD);
+    const double nan = std::numeric_limits<double>::quiet_NaN();
+    int done = 0;           // sweep i reads buf[i & 1] and writes buf[(i + 1) & 1]
+
+    const bool screened = !exact_cd && tol > 0.0 && !c->exact_stop && c->screen_stop &&
+                          c->sweep_kernel != 1 && sweep_tile_covers(r, b) &&
+                          sub_iter <= SCREEN_MAX_SWEEPS && keep_sweeping(1.0, tol);
+    if (screened) {
+        // All sweeps and their verdict kernels are enqueued without host round trips; sweeps after a
+        // "stop"/"inconclusive" verdict return at once and leave both code buffers untouched.
+        ONMF_TRY(onmf_reserve(c, c->screen, (size_t)ScreenLayout::TOTAL * sizeof(float), "stop-test screen"));
+        float* base = (float*)c->screen.p;
+        const ScreenDev sc = screen_pointers(base);
+        ONMF_TRY(launch_screen_init(c, base, r, s));
+        int start = 0;
+        while (start < sub_iter) {
+            for (int i = start; i < sub_iter; ++i) {
+                const float damp = (float)std::sqrt((double)i + 10.0);
+                int groups = 0;
+                ONMF_TRY(profile_mark(c, s));
+                ONMF_TRY(launch_sweep(c, r, b, Gm, Cm, buf[i & 1], buf[(i + 1) & 1], alpha, damp, 0,
+                                      (double*)c->stats.p, &groups, s, &sc));
+                ONMF_TRY(profile_mark(c, s));
+                ONMF_TRY(launch_screen_refresh(c, base, r, b, buf[(i + 1) & 1], buf[i & 1], s));
+                ONMF_TRY(launch_screen_decide(c, base, r, i, (float)tol, (float)rank_cap, s));
             }
+            HIP_TRY(c, hipMemcpyAsync(c->pinned, base + ScreenLayout::REC,
+                                      (size_t)4 * SCREEN_MAX_SWEEPS * sizeof(float), hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipStreamSynchronize(s));
+            const float* rec = (const float*)c->pinned;
+            int next_start = sub_iter;
+            bool stop = false;
+            for (int i = start; i < sub_iter; ++i) {
+                const int code = (int)rec[4 * i + 2];     // 1 continue, 2 stop, 3 inconclusive
+                if (code == 0)
+                    return onmf_fail(c, ONMF_ERR_HIP, "sparse_code: sweep %d left no verdict", i);
+                done = i + 1;
+                if (code == 1) {
+                    if (dist_trace) dist_trace[i] = rec[4 * i + 0];
+                    continue;
+                }
+                if (code == 2) {
+                    if (dist_trace) dist_trace[i] = rec[4 * i + 1];
+                    stop = true;
+                    break;
+                }
+                double dist = nan;                        // bounds straddle tol: evaluate in full
+                ONMF_TRY(exact_dist(c, r, b, buf[(i + 1) & 1], buf[i & 1], s, &dist));
+                if (dist_trace) dist_trace[i] = (float)dist;
+                if (!keep_sweeping(dist, tol)) { stop = true; break; }
+                if (i + 1 < sub_iter) ONMF_TRY(launch_screen_clear_flag(c, base, s));
+                next_start = i + 1;
+                break;
+            }
+            if (stop) break;
+            start = next_start;
         }
-        if (!decided) {
-            // full test: sigma_max via the r x r Gram matrices of (H - H_prev) and H_prev
-            ONMF_TRY(onmf_reserve(c, c->dbuf, rb * sizeof(float), "code difference"));
-            ONMF_TRY(onmf_reserve(c, c->small, (size_t)2 * r * r * sizeof(float), "stop-test Grams"));
-            float* D = (float*)c->dbuf.p;
-            float* G1 = (float*)c->small.p;
-            float* G0 = G1 + (size_t)r * r;
-            ONMF_TRY(launch_sub(D, nxt, cur, rb, s));
-            ONMF_TRY(launch_gemm(c, false, false, r, r, b, D, b, D, b, 1.f, 0.f, nullptr, G1, r, s));
-            ONMF_TRY(launch_gemm(c, false, false, r, r, b, cur, b, cur, b, 1.f, 0.f, nullptr, G0, r, s));
-            HIP_TRY(c, hipMemcpyAsync(c->pinned, G1, (size_t)2 * r * r * sizeof(float),
+    } else {
+        double dist = 1.0;      // src/onmf.py:251
+        while (done < sub_iter && keep_sweeping(dist, tol)) {
+            float* cur = buf[done & 1];
+            float* nxt = buf[(done + 1) & 1];
+            const float damp = (float)std::sqrt((double)done + 10.0);
+            int groups = 0;
+            ONMF_TRY(profile_mark(c, s));
+            ONMF_TRY(launch_sweep(c, r, b, Gm, Cm, cur, nxt, alpha, damp, exact_cd, (double*)c->stats.p,
+                                  &groups, s));
+            ONMF_TRY(profile_mark(c, s));
+            HIP_TRY(c, hipMemcpyAsync(c->pinned, c->stats.p, (size_t)groups * 2 * sizeof(double),
                                       hipMemcpyDeviceToHost, s));
             HIP_TRY(c, hipStreamSynchronize(s));
-            const float* hg = (const float*)c->pinned;
-            const double l1 = host_lambda_max(hg, r);
-            const double l0 = host_lambda_max(hg + (size_t)r * r, r);
-            dist = std::sqrt(std::max(l1, 0.0)) / std::sqrt(std::max(l0, 0.0));
-            shown = dist;
+            const double* hs = (const double*)c->pinned;
+            double dsum = 0.0, hsum = 0.0;
+            for (int g = 0; g < groups; ++g) {
+                dsum += hs[2 * g];
+                hsum += hs[2 * g + 1];
+            }
+            // Decide `dist > tol` from Frobenius norms when they settle it:
+            //   s1 in [fD / sqrt(rank), fD],  s0 in [fH / sqrt(rank), fH]   (fD, fH Frobenius norms)
+            bool decided = false;
+            double shown = nan;
+            const double fD = std::sqrt(dsum), fH = std::sqrt(hsum);
+            if (exact_cd) {
+                // fixed-point iteration of the convex problem: stop on the relative Frobenius change
+                dist = (hsum == 0.0) ? (dsum == 0.0 ? 0.0 : std::numeric_limits<double>::infinity())
+                                     : fD / fH;
+                decided = true;
+                shown = dist;
+            } else if (!c->exact_stop) {
+                if (hsum == 0.0) {                // s0 == 0: dist is NaN (stop) or +inf (continue)
+                    dist = (dsum == 0.0) ? nan : std::numeric_limits<double>::infinity();
+                    decided = true;
+                    shown = dist;
+                } else if (dsum == 0.0) {
+                    dist = 0.0;
+                    decided = true;
+                    shown = 0.0;
+                } else if (tol < 0.0) {
+                    dist = 1.0;                   // any positive value compares the same way
+                    decided = true;
+                } else {
+                    const double lower = (fD / std::sqrt(rank_cap)) / fH * (1.0 - 1e-4);
+                    const double upper = fD / (fH / std::sqrt(rank_cap)) * (1.0 + 1e-4);
+                    if (lower > tol) { dist = lower; decided = true; shown = lower; }
+                    else if (upper <= tol) { dist = upper; decided = true; shown = upper; }
+                }
+            }
+            if (!decided) {
+                ONMF_TRY(exact_dist(c, r, b, nxt, cur, s, &dist));
+                shown = dist;
+            }
+            if (dist_trace) dist_trace[done] = (float)shown;
+            ++done;
         }
-        if (dist_trace) dist_trace[done] = (float)shown;
-        std::swap(cur, nxt);
-        ++done;
     }
-    HIP_TRY(c, hipMemcpyAsync(H, cur, rb * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(H, buf[done & 1], rb * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (sweeps_done) *sweeps_done = done;
     if (dist_trace)
         for (int i = done; i < sub_iter; ++i) dist_trace[i] = std::numeric_limits<float>::quiet_NaN();

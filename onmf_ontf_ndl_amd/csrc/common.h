@@ -44,10 +44,12 @@ struct onmf_ctx {
     std::vector<hipEvent_t> ev;     // pairs of events bracketing sweep launches
     int ev_used = 0;
     DevBuf dbuf;                    // H - H_prev for the exact stopping test (r x b)
+    DevBuf screen;                  // stopping-test screen state (ScreenLayout)
     DevBuf slab_side;               // split-K slabs of products issued on the side stream
     hipStream_t side = nullptr;     // dictionary pass runs here, beside the code solve
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int overlap_dict = 1;
+    int screen_stop = 1;
 };
 
 int onmf_fail(onmf_ctx* c, int code, const char* fmt, ...);
@@ -77,11 +79,45 @@ int launch_gemm(onmf_ctx* c, bool a_km, bool b_kn, int M, int N, int K, const fl
                 const float* B, int ldb, float alpha, float beta, const float* Cin, float* C,
                 int ldc, hipStream_t s, DevBuf* slab = nullptr);
 
+// Device pointers of the stopping-test screen (screen.hip); all inside one allocation.
+struct ScreenDev {
+    const float* ublk;   // NB swizzled 16x16 blocks of U^T (16 unit probe vectors, r_pad long)
+    const float* v;      // r_pad: positive vector of the Collatz-Wielandt bound
+    float* zacc;         // r_pad x 16: power-step accumulator
+    float* p2acc;        // 16: probe energies
+    float* yacc;         // r_pad: H (H^T v)
+    double* sums;        // [0] = sum (H_new - H_old)^2, [1] = sum H_old^2
+    const int* flag;     // 0 = keep sweeping
+};
+
 // One Gauss-Seidel sweep over all rows: Hout = sweep(Hin).  stats (device, 2 doubles per
 // workgroup) receives sum((Hout-Hin)^2) and sum(Hin^2) partials; *n_groups = number of pairs.
 int launch_sweep(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm, const float* Hin,
                  float* Hout, float alpha, float damp, int exact_cd, double* stats, int* n_groups,
-                 hipStream_t s);
+                 hipStream_t s, const ScreenDev* screen = nullptr);
+bool sweep_tile_covers(int r, int b);
+
+// Stopping-test screen: state layout, initialisation and the per-sweep decision kernel.
+constexpr int SCREEN_MAX_SWEEPS = 64;
+struct ScreenLayout {           // offsets in floats into ctx->screen
+    static constexpr int UBLK = 0;                 // 16 * 256
+    static constexpr int V = 4096;                 // 256
+    static constexpr int ZACC = V + 256;           // 256 * 16
+    static constexpr int P2ACC = ZACC + 4096;      // 16
+    static constexpr int YACC = P2ACC + 16;        // 256
+    static constexpr int SUMS = YACC + 256;        // 2 doubles (8-byte aligned)
+    static constexpr int FLAG = SUMS + 4;          // int
+    static constexpr int UBPREV = FLAG + 1;        // float: upper bound of sigma_max(H before the sweep)
+    static constexpr int REC = FLAG + 4;           // SCREEN_MAX_SWEEPS x 4 floats
+    static constexpr int TOTAL = REC + 4 * SCREEN_MAX_SWEEPS;
+};
+ScreenDev screen_pointers(float* base);
+int launch_screen_init(onmf_ctx* c, float* base, int r, hipStream_t s);
+int launch_screen_decide(onmf_ctx* c, float* base, int r, int sweep_index, float tol, float rank_cap,
+                         hipStream_t s);
+int launch_screen_clear_flag(onmf_ctx* c, float* base, hipStream_t s);
+int launch_screen_refresh(onmf_ctx* c, float* base, int r, int b, const float* Hnew, const float* Hold,
+                          hipStream_t s);
 
 int launch_dict_pass(onmf_ctx* c, int d, int r, const float* Win, const float* A, const float* B,
                      float* Wout, hipStream_t s);

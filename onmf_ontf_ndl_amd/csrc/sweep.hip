@@ -85,19 +85,42 @@ __device__ __forceinline__ int blk_index(int K, int J) {
     return HALF ? (K * (K + 1) / 2 + J) : (K * NB + J);
 }
 
-template <int NB, bool HALF>
+// sum over the 16 lanes of a DPP row (lanes 16g..16g+15); the total lands in lane 16g+15
+__device__ __forceinline__ float row_sum16(float x) {
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x111, 0xf, 0xf, true));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x112, 0xf, 0xf, true));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x114, 0xf, 0xf, true));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x118, 0xf, 0xf, true));
+    return x;
+}
+
+// PROBE = true adds what the stopping test needs without a second pass over H (see screen.hip):
+//   * P = U^T (H_new - H_old) for 16 unit probe vectors U (4 extra MFMAs per block) and, per probe,
+//     sum_c P[p][c]^2  -> a rigorous lower bound of sigma_max(H_new - H_old)^2;
+//   * y = H_new (H_new^T v) for a positive vector v -> Collatz-Wielandt upper bound of
+//     sigma_max(H_new)^2 (H H^T is entrywise nonnegative), used by the NEXT sweep's test;
+// (The power step that refreshes the probe subspace runs on a sample of the columns in its own
+// small kernel, screen.hip.)
+template <int NB, bool HALF, bool PROBE>
 __global__ __launch_bounds__(TILE_WAVES * 64) void sweep_tile_kernel(
     int r, int b, const float* __restrict__ Gm, const float* __restrict__ Cm,
     const float* __restrict__ Hin, float* __restrict__ Hout, float alpha, float rdamp, int exact_cd,
-    double* __restrict__ stats) {
+    double* __restrict__ stats, ScreenDev sc) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NBLK = HALF ? NB * (NB + 1) / 2 : NB * NB;
-    float* Gs = lds;                       // NBLK blocks
-    float* Ls = lds + NBLK * 256;          // NB blocks: strictly-lower part of the diagonal blocks
-    float* steps = Ls + NB * 256;          // 16*NB step sizes (0 for padded rows)
+    float* Gs = lds;                       // NBLK swizzled 16x16 blocks of Gm
+    float* steps = lds + NBLK * 256;       // 16*NB step sizes (0 for padded rows)
+    float* Us = steps + 16 * NB;           // PROBE: NB swizzled blocks of U^T
+    float* vs = Us + NB * 256;             // PROBE: v
+    float* ywg = vs + 16 * NB;             // PROBE: workgroup partial of y
+    float* p2wg = ywg + 16 * NB;           // PROBE: workgroup partial of the 16 probe energies
+
+    const int tid = threadIdx.x;
+    if (PROBE) {
+        if (*sc.flag != 0) return;         // an earlier sweep's test ended the loop (grid-uniform)
+    }
 
     // ---- stage Gm into LDS (whole workgroup) ----
-    const int tid = threadIdx.x;
     for (int K = 0; K < NB; ++K) {
         const int jend = HALF ? (K + 1) : NB;
         for (int e = tid; e < jend * 256; e += TILE_WAVES * 64) {
@@ -105,7 +128,6 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void sweep_tile_kernel(
             const int row = 16 * K + i, col = 16 * J + j;
             const float v = (row < r && col < r) ? Gm[(size_t)row * r + col] : 0.f;
             Gs[blk_index<NB, HALF>(K, J) * 256 + blk_off(i, j)] = v;
-            if (J == K) Ls[K * 256 + blk_off(i, j)] = (j < i) ? v : 0.f;
         }
     }
     for (int k = tid; k < 16 * NB; k += TILE_WAVES * 64) {
@@ -115,6 +137,14 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void sweep_tile_kernel(
             st = exact_cd ? (gkk > 0.f ? 1.0f / gkk : 0.f) : rdamp / (gkk + 1.0f);
         }
         steps[k] = st;
+        if (PROBE) {
+            vs[k] = sc.v[k];
+            ywg[k] = 0.f;
+        }
+    }
+    if (PROBE) {
+        for (int e = tid; e < NB * 256; e += TILE_WAVES * 64) Us[e] = sc.ublk[e];
+        if (tid < 16) p2wg[tid] = 0.f;
     }
     __syncthreads();
 
@@ -149,19 +179,26 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void sweep_tile_kernel(
             hsum = fmaf(v, v, hsum);
         }
     }
+    f32x4 pacc = {0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll
     for (int K = 0; K < NB; ++K) {
         // keep the compiler from hoisting later blocks' LDS reads above this point (register budget)
         __builtin_amdgcn_sched_barrier(0);
         // Cm is touched once per sweep: fetch this block's four values now, use them after the MFMAs
+        // (row offsets are recomputed from an opaque copy of b per block: kept as common
+        // subexpressions, the 4*NB scalar offsets would occupy most of the scalar register file)
+        int bk = b;
+        asm volatile("" : "+s"(bk));
         float cmk[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t)
-            cmk[t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_c, voff, (16 * K + t) * b * 4, 0));
+            cmk[t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_c, voff, (16 * K + t) * bk * 4, 0));
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int J = 0; J < NB; ++J) {
+            // bound how many A-operand reads are in flight at once (register budget: 128 per lane)
+            if (NB > 8 && J > 0 && (J % 6) == 0) __builtin_amdgcn_sched_barrier(0);
             float a0, a1, a2, a3;
             if (!HALF || J <= K) {
                 const float4 a = *reinterpret_cast<const float4*>(
@@ -187,17 +224,20 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void sweep_tile_kernel(
         // deltas would pollute the statistics): step 0
         const float st[4] = {cvalid ? st4.x : 0.f, cvalid ? st4.y : 0.f, cvalid ? st4.z : 0.f,
                              cvalid ? st4.w : 0.f};
+        float hold4[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) hold4[t] = h[K][t];
 
 #pragma unroll
         for (int Q = 0; Q < 4; ++Q) {
             const bool own = (g == Q);
-            // Lq[t][tj] = strictly-lower Gm[16K+4g+t][16K+4Q+tj]
-            float Lq[4][4];
+            // Gq[t][tj] = Gm[16K+4g+t][16K+4Q+tj] from the diagonal block (rows 4g+t, column quad Q)
+            float Gq[4][4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const float4 v = *reinterpret_cast<const float4*>(
-                    Ls + K * 256 + (4 * g + t) * 16 + 4 * (Q ^ ((-g) & 3)));
-                Lq[t][0] = v.x; Lq[t][1] = v.y; Lq[t][2] = v.z; Lq[t][3] = v.w;
+                    Gs + blk_index<NB, HALF>(K, K) * 256 + (4 * g + t) * 16 + 4 * (Q ^ ((-g) & 3)));
+                Gq[t][0] = v.x; Gq[t][1] = v.y; Gq[t][2] = v.z; Gq[t][3] = v.w;
             }
             float dq[4];
 #pragma unroll
@@ -209,28 +249,40 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void sweep_tile_kernel(
                 h[K][tj] = own ? hnew : hold;
                 dsum = fmaf(dl, dl, dsum);
                 dq[tj] = dl;
+                // rows of this quad that come later (owner lanes only: elsewhere dl == 0)
 #pragma unroll
-                for (int t = tj + 1; t < 4; ++t) acc[t] = fmaf(Lq[t][tj], dl, acc[t]);
+                for (int t = tj + 1; t < 4; ++t) acc[t] = fmaf(Gq[t][tj], dl, acc[t]);
             }
             if (Q < 3) {
+                // push the four deltas into the rows of the lane groups that come later in the block
+                const bool later = (g > Q);
 #pragma unroll
                 for (int tj = 0; tj < 4; ++tj) {
                     const float all = __shfl(dq[tj], 16 * Q + c, 64);
-                    const float other = own ? 0.f : all;
+                    const float other = later ? all : 0.f;
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) acc[t] = fmaf(Lq[t][tj], other, acc[t]);
+                    for (int t = 0; t < 4; ++t) acc[t] = fmaf(Gq[t][tj], other, acc[t]);
                 }
             }
             asm volatile("" : "+v"(dsum));     // keep the running sum current (no deferred chain)
+        }
+        if (PROBE) {
+            const float4 u4 = *reinterpret_cast<const float4*>(Us + K * 256 + c * 16 + 4 * (g ^ sw_c));
+            pacc = __builtin_amdgcn_mfma_f32_16x16x4f32(u4.x, h[K][0] - hold4[0], pacc, 0, 0, 0);
+            pacc = __builtin_amdgcn_mfma_f32_16x16x4f32(u4.y, h[K][1] - hold4[1], pacc, 0, 0, 0);
+            pacc = __builtin_amdgcn_mfma_f32_16x16x4f32(u4.z, h[K][2] - hold4[2], pacc, 0, 0, 0);
+            pacc = __builtin_amdgcn_mfma_f32_16x16x4f32(u4.w, h[K][3] - hold4[3], pacc, 0, 0, 0);
         }
     }
 
 #pragma unroll
     for (int J = 0; J < NB; ++J) {
+        int bj = b;
+        asm volatile("" : "+s"(bj));
 #pragma unroll
         for (int t = 0; t < 4; ++t)
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(h[J][t]), rs_o, voff_st,
-                                                  (16 * J + t) * b * 4, 0);
+                                                  (16 * J + t) * bj * 4, 0);
     }
     double ds = dsum, hh = hsum;
 #pragma unroll
@@ -242,26 +294,67 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void sweep_tile_kernel(
         const int slot = blockIdx.x * TILE_WAVES + wave;
         stats[2 * slot + 0] = ds;
         stats[2 * slot + 1] = hh;
+        if (PROBE) {
+            atomicAdd(&sc.sums[0], ds);
+            atomicAdd(&sc.sums[1], hh);
+        }
+    }
+
+    if (PROBE) {
+        __builtin_amdgcn_sched_barrier(0);
+        // energy of each probe's projection over this wave's columns: lane (c,g) reg t = probe 4g+t
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float e = row_sum16(pacc[t] * pacc[t]);
+            if (c == 15) atomicAdd(&p2wg[4 * g + t], e);
+        }
+        // Collatz-Wielandt: ph[c] = sum_rows v[row] * H_new[row][c], then y[row] += H_new[row][c] * ph[c]
+        float ph = 0.f;
+#pragma unroll
+        for (int J = 0; J < NB; ++J) {
+            if ((J & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+            const float4 v4 = *reinterpret_cast<const float4*>(vs + 16 * J + 4 * g);
+            ph = fmaf(v4.x, h[J][0], ph);
+            ph = fmaf(v4.y, h[J][1], ph);
+            ph = fmaf(v4.z, h[J][2], ph);
+            ph = fmaf(v4.w, h[J][3], ph);
+        }
+        ph += __shfl_xor(ph, 16);
+        ph += __shfl_xor(ph, 32);
+#pragma unroll
+        for (int J = 0; J < NB; ++J) {
+            __builtin_amdgcn_sched_barrier(0);     // one block at a time: bounded register use
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float e = row_sum16(h[J][t] * ph);
+                if (c == 15) atomicAdd(&ywg[16 * J + 4 * g + t], e);
+            }
+        }
+        __syncthreads();
+        for (int k = tid; k < 16 * NB; k += TILE_WAVES * 64) atomicAdd(&sc.yacc[k], ywg[k]);
+        if (tid < 16) atomicAdd(&sc.p2acc[tid], p2wg[tid]);
     }
 }
 
-template <int NB, bool HALF>
+template <int NB, bool HALF, bool PROBE>
 int run_tile(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm, const float* Hin, float* Hout,
-             float alpha, float damp, int exact_cd, double* stats, int* n_groups, hipStream_t s) {
+             float alpha, float damp, int exact_cd, double* stats, int* n_groups, const ScreenDev& sc,
+             hipStream_t s) {
     constexpr int NBLK = HALF ? NB * (NB + 1) / 2 : NB * NB;
-    constexpr size_t lds = sizeof(float) * ((size_t)NBLK * 256 + NB * 256 + NB * 16);
+    constexpr size_t lds = sizeof(float) * ((size_t)NBLK * 256 + NB * 16 +
+                                            (PROBE ? (NB * 256 + 2 * NB * 16 + 16) : 0));
     static_assert(lds <= 160 * 1024, "Gm blocks do not fit the LDS");
     static bool attr_done = false;
     if (!attr_done) {
-        HIP_TRY(c, hipFuncSetAttribute((const void*)sweep_tile_kernel<NB, HALF>,
+        HIP_TRY(c, hipFuncSetAttribute((const void*)sweep_tile_kernel<NB, HALF, PROBE>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
     const int cols_per_wg = TILE_WAVES * 16;
     const int wgs = (b + cols_per_wg - 1) / cols_per_wg;
     *n_groups = wgs * TILE_WAVES;
-    hipLaunchKernelGGL((sweep_tile_kernel<NB, HALF>), dim3(wgs), dim3(TILE_WAVES * 64), lds, s, r, b, Gm,
-                       Cm, Hin, Hout, alpha, 1.0f / damp, exact_cd, stats);
+    hipLaunchKernelGGL((sweep_tile_kernel<NB, HALF, PROBE>), dim3(wgs), dim3(TILE_WAVES * 64), lds, s, r, b,
+                       Gm, Cm, Hin, Hout, alpha, 1.0f / damp, exact_cd, stats, sc);
     HIP_TRY(c, hipGetLastError());
     return ONMF_OK;
 }
@@ -287,19 +380,28 @@ static int launch_sweep_column(onmf_ctx* c, int r, int b, const float* Gm, const
     return ONMF_OK;
 }
 
+bool sweep_tile_covers(int r, int b) {
+    return (r + 15) / 16 <= 16 && (double)r * (double)b * 4.0 < 2147483000.0;
+}
+
 int launch_sweep(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm, const float* Hin,
                  float* Hout, float alpha, float damp, int exact_cd, double* stats, int* n_groups,
-                 hipStream_t s) {
+                 hipStream_t s, const ScreenDev* screen) {
     const int nb = (r + 15) / 16;
-    const bool fits_i32 = (double)r * (double)b * 4.0 < 2147483000.0;
-    const bool want_tile = fits_i32 && ((c->sweep_kernel == 2) || (c->sweep_kernel == 0 && nb <= 16));
-    if (!want_tile || nb > 16) {
+    const bool want_tile = sweep_tile_covers(r, b) && (c->sweep_kernel == 2 || c->sweep_kernel == 0);
+    if (!want_tile) {
         if (c->sweep_kernel == 2)
             return onmf_fail(c, ONMF_ERR_ARG, "sweep: the tile kernel covers r <= 256 (r=%d)", r);
+        if (screen) return onmf_fail(c, ONMF_ERR_ARG, "sweep: probes need the tile kernel");
         return launch_sweep_column(c, r, b, Gm, Cm, Hin, Hout, alpha, damp, exact_cd, stats, n_groups, s);
     }
-#define TILE_CASE(NBV, HALFV) \
-    case NBV: return run_tile<NBV, HALFV>(c, r, b, Gm, Cm, Hin, Hout, alpha, damp, exact_cd, stats, n_groups, s)
+    ScreenDev none = {};
+#define TILE_CASE(NBV, HALFV)                                                                          \
+    case NBV:                                                                                          \
+        return screen ? run_tile<NBV, HALFV, true>(c, r, b, Gm, Cm, Hin, Hout, alpha, damp, exact_cd,   \
+                                                   stats, n_groups, *screen, s)                        \
+                      : run_tile<NBV, HALFV, false>(c, r, b, Gm, Cm, Hin, Hout, alpha, damp, exact_cd,  \
+                                                    stats, n_groups, none, s)
     switch (nb) {
         TILE_CASE(1, false);
         TILE_CASE(2, false);
