@@ -88,7 +88,8 @@ static double tridiag_top(const std::vector<double>& a, const std::vector<double
     return 0.5 * (lo + hi);
 }
 
-double host_lambda_max(const float* S, int n) {
+// `enough` > 0: return as soon as a Ritz value (always a lower bound of the top eigenvalue) reaches it.
+static double lambda_max_impl(const float* S, int n, double enough) {
     if (n <= 0) return 0.0;
     if (n == 1) return (double)S[0];
     double fro = 0.0;
@@ -129,6 +130,7 @@ double host_lambda_max(const float* S, int n) {
         for (int i = 0; i < n; ++i) bn += w[i] * w[i];
         bn = std::sqrt(bn);
         theta = tridiag_top(al, be, j + 1);
+        if (enough > 0.0 && theta >= enough) break;
         if (bn <= 1e-14 * std::sqrt(fro) || j + 1 == mmax) break;
         if (n > 48) {       // small matrices run the full n steps (exact); larger ones stop on stagnation
             if (std::fabs(theta - prev) <= 4e-16 * std::fabs(theta)) ++calm; else calm = 0;
@@ -141,6 +143,8 @@ double host_lambda_max(const float* S, int n) {
     }
     return theta;
 }
+
+double host_lambda_max(const float* S, int n) { return lambda_max_impl(S, n, 0.0); }
 
 // ---------------------------------------------------------------------------------------------
 // ABI
@@ -236,23 +240,37 @@ static bool keep_sweeping(double dist, double tol) { return dist > tol; }
 
 // Full stopping test of one sweep: dist = sigma_max(Hnew - Hold) / sigma_max(Hold) through the two
 // r x r Gram matrices (MFMA products) and their top eigenvalues (host, double).  Synchronises s.
+// With ub_old > 0 (a rigorous upper bound of sigma_max(Hold)) and tol > 0 the cheap half is tried
+// first: only the Gram of the difference is formed, and the Lanczos run on it stops as soon as a
+// Ritz value (a lower bound of its top eigenvalue) proves dist > tol; *dist is then that bound.
 static int exact_dist(onmf_ctx* c, int r, int b, const float* Hnew, const float* Hold, hipStream_t s,
-                      double* dist) {
+                      double* dist, double ub_old = -1.0, double tol = -1.0) {
     const size_t rb = (size_t)r * b;
+    const size_t rr = (size_t)r * r;
     ONMF_TRY(onmf_reserve(c, c->dbuf, rb * sizeof(float), "code difference"));
-    ONMF_TRY(onmf_reserve(c, c->small, (size_t)2 * r * r * sizeof(float), "stop-test Grams"));
-    ONMF_TRY(onmf_reserve_pinned(c, (size_t)2 * r * r * sizeof(float)));
+    ONMF_TRY(onmf_reserve(c, c->small, 2 * rr * sizeof(float), "stop-test Grams"));
+    ONMF_TRY(onmf_reserve_pinned(c, 2 * rr * sizeof(float)));
     float* D = (float*)c->dbuf.p;
     float* G1 = (float*)c->small.p;
-    float* G0 = G1 + (size_t)r * r;
+    float* G0 = G1 + rr;
+    const float* hg = (const float*)c->pinned;
     ONMF_TRY(launch_sub(D, Hnew, Hold, rb, s));
     ONMF_TRY(launch_gemm(c, false, false, r, r, b, D, b, D, b, 1.f, 0.f, nullptr, G1, r, s));
+    if (ub_old > 0.0 && tol > 0.0) {
+        HIP_TRY(c, hipMemcpyAsync(c->pinned, G1, rr * sizeof(float), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        const double need = (tol * ub_old) * (tol * ub_old) * (1.0 + 2e-4);   // margin: fp32 Gram rounding
+        const double th = lambda_max_impl(hg, r, need);
+        if (th >= need) {
+            *dist = std::sqrt(th) / ub_old;
+            return ONMF_OK;
+        }
+    }
     ONMF_TRY(launch_gemm(c, false, false, r, r, b, Hold, b, Hold, b, 1.f, 0.f, nullptr, G0, r, s));
-    HIP_TRY(c, hipMemcpyAsync(c->pinned, G1, (size_t)2 * r * r * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(c->pinned, G1, 2 * rr * sizeof(float), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
-    const float* hg = (const float*)c->pinned;
     const double l1 = host_lambda_max(hg, r);
-    const double l0 = host_lambda_max(hg + (size_t)r * r, r);
+    const double l0 = host_lambda_max(hg + rr, r);
     *dist = std::sqrt(std::max(l1, 0.0)) / std::sqrt(std::max(l0, 0.0));
     return ONMF_OK;
 }
@@ -333,7 +351,7 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
                     break;
                 }
                 double dist = nan;                        // bounds straddle tol: evaluate in full
-                ONMF_TRY(exact_dist(c, r, b, buf[(i + 1) & 1], buf[i & 1], s, &dist));
+                ONMF_TRY(exact_dist(c, r, b, buf[(i + 1) & 1], buf[i & 1], s, &dist, (double)rec[4 * i + 3], tol));
                 if (dist_trace) dist_trace[i] = (float)dist;
                 if (!keep_sweeping(dist, tol)) { stop = true; break; }
                 if (i + 1 < sub_iter) ONMF_TRY(launch_screen_clear_flag(c, base, s));

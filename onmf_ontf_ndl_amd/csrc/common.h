@@ -50,6 +50,7 @@ struct onmf_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int overlap_dict = 1;
     int screen_stop = 1;
+    int screen_r = -1;              // r of the probes currently held in `screen`
 };
 
 int onmf_fail(onmf_ctx* c, int code, const char* fmt, ...);
@@ -83,10 +84,10 @@ int launch_gemm(onmf_ctx* c, bool a_km, bool b_kn, int M, int N, int K, const fl
 struct ScreenDev {
     const float* ublk;   // NB swizzled 16x16 blocks of U^T (16 unit probe vectors, r_pad long)
     const float* v;      // r_pad: positive vector of the Collatz-Wielandt bound
-    float* zacc;         // r_pad x 16: power-step accumulator
-    float* p2acc;        // 16: probe energies
-    float* yacc;         // r_pad: H (H^T v)
-    double* sums;        // [0] = sum (H_new - H_old)^2, [1] = sum H_old^2
+    float* zacc;         // ZREPL x r_pad x 16: power-step accumulator
+    float* p2acc;        // REPL x 16: probe energies
+    float* yacc;         // REPL x 256: H (H^T v)
+    double* sums;        // REPL x {sum (H_new - H_old)^2, sum H_old^2}
     const int* flag;     // 0 = keep sweeping
 };
 
@@ -99,18 +100,22 @@ bool sweep_tile_covers(int r, int b);
 
 // Stopping-test screen: state layout, initialisation and the per-sweep decision kernel.
 constexpr int SCREEN_MAX_SWEEPS = 64;
+constexpr int SCREEN_REPL = 8;       // replicas of the sweep kernel's accumulators (atomic contention)
+constexpr int SCREEN_ZREPL = 4;      // replicas of the power-step accumulator
 struct ScreenLayout {           // offsets in floats into ctx->screen
-    static constexpr int UBLK = 0;                 // 16 * 256
-    static constexpr int V = 4096;                 // 256
-    static constexpr int ZACC = V + 256;           // 256 * 16
-    static constexpr int P2ACC = ZACC + 4096;      // 16
-    static constexpr int YACC = P2ACC + 16;        // 256
-    static constexpr int SUMS = YACC + 256;        // 2 doubles (8-byte aligned)
-    static constexpr int FLAG = SUMS + 4;          // int
+    static constexpr int UBLK = 0;                                 // 16 * 256
+    static constexpr int V = 4096;                                 // 256
+    static constexpr int ZACC = V + 256;                           // ZREPL x 256 x 16
+    static constexpr int P2ACC = ZACC + SCREEN_ZREPL * 4096;       // REPL x 16
+    static constexpr int YACC = P2ACC + SCREEN_REPL * 16;          // REPL x 256
+    static constexpr int SUMS = YACC + SCREEN_REPL * 256;          // REPL x 2 doubles (8-byte aligned)
+    static constexpr int FLAG = SUMS + SCREEN_REPL * 4;            // int
     static constexpr int UBPREV = FLAG + 1;        // float: upper bound of sigma_max(H before the sweep)
-    static constexpr int REC = FLAG + 4;           // SCREEN_MAX_SWEEPS x 4 floats
+    static constexpr int AVEC = FLAG + 4;          // 16: last Ritz coefficient vector (warm start)
+    static constexpr int REC = AVEC + 16;          // SCREEN_MAX_SWEEPS x 4 floats
     static constexpr int TOTAL = REC + 4 * SCREEN_MAX_SWEEPS;
 };
+static_assert(ScreenLayout::SUMS % 2 == 0, "double alignment");
 ScreenDev screen_pointers(float* base);
 int launch_screen_init(onmf_ctx* c, float* base, int r, hipStream_t s);
 int launch_screen_decide(onmf_ctx* c, float* base, int r, int sweep_index, float tol, float rank_cap,

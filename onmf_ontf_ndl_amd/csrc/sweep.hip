@@ -114,6 +114,7 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void sweep_tile_kernel(
     float* vs = Us + NB * 256;             // PROBE: v
     float* ywg = vs + 16 * NB;             // PROBE: workgroup partial of y
     float* p2wg = ywg + 16 * NB;           // PROBE: workgroup partial of the 16 probe energies
+    double* sumwg = reinterpret_cast<double*>(p2wg + 16);   // PROBE: workgroup partial of the two sums
 
     const int tid = threadIdx.x;
     if (PROBE) {
@@ -145,6 +146,7 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void sweep_tile_kernel(
     if (PROBE) {
         for (int e = tid; e < NB * 256; e += TILE_WAVES * 64) Us[e] = sc.ublk[e];
         if (tid < 16) p2wg[tid] = 0.f;
+        if (tid < 2) sumwg[tid] = 0.0;
     }
     __syncthreads();
 
@@ -295,8 +297,8 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void sweep_tile_kernel(
         stats[2 * slot + 0] = ds;
         stats[2 * slot + 1] = hh;
         if (PROBE) {
-            atomicAdd(&sc.sums[0], ds);
-            atomicAdd(&sc.sums[1], hh);
+            atomicAdd(&sumwg[0], ds);
+            atomicAdd(&sumwg[1], hh);
         }
     }
 
@@ -331,8 +333,11 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void sweep_tile_kernel(
             }
         }
         __syncthreads();
-        for (int k = tid; k < 16 * NB; k += TILE_WAVES * 64) atomicAdd(&sc.yacc[k], ywg[k]);
-        if (tid < 16) atomicAdd(&sc.p2acc[tid], p2wg[tid]);
+        // one set of global atomics per workgroup, spread over replicas to keep contention low
+        const int rep = blockIdx.x % SCREEN_REPL;
+        for (int k = tid; k < 16 * NB; k += TILE_WAVES * 64) atomicAdd(&sc.yacc[rep * 256 + k], ywg[k]);
+        if (tid < 16) atomicAdd(&sc.p2acc[rep * 16 + tid], p2wg[tid]);
+        if (tid < 2) atomicAdd(&sc.sums[rep * 2 + tid], sumwg[tid]);
     }
 }
 
@@ -342,7 +347,7 @@ int run_tile(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm, const 
              hipStream_t s) {
     constexpr int NBLK = HALF ? NB * (NB + 1) / 2 : NB * NB;
     constexpr size_t lds = sizeof(float) * ((size_t)NBLK * 256 + NB * 16 +
-                                            (PROBE ? (NB * 256 + 2 * NB * 16 + 16) : 0));
+                                            (PROBE ? (NB * 256 + 2 * NB * 16 + 16 + 4) : 0));
     static_assert(lds <= 160 * 1024, "Gm blocks do not fit the LDS");
     static bool attr_done = false;
     if (!attr_done) {
