@@ -1,0 +1,91 @@
+"""The device-side screen of the stopping test must reach the verdicts of the full test.
+
+Sweep counts and codes are compared between ONMF_OPT_EXACT_STOP (every test evaluated in full, the
+reference's arithmetic) and the default path (rigorous bounds, full test only where they straddle
+stopping_diff), including thresholds placed right next to an actual dist value so that the bounds
+cannot decide and the fallback has to."""
+import numpy as np
+import pytest
+
+from conftest import relerr
+
+pytestmark = pytest.mark.gpu
+
+EXACT, SCREEN = 2, 5
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from onmf_ontf_ndl_amd.engine import get_engine
+    e = get_engine()
+    yield e
+    e.set_option(EXACT, 0)
+    e.set_option(SCREEN, 1)
+
+
+def host(t):
+    return t.detach().cpu().numpy().astype(np.float64)
+
+
+def both(eng, X, W, H0, tol, alpha=0.0):
+    eng.set_option(EXACT, 1)
+    He, se, de = eng.sparse_code(X, W, H0=H0, alpha=alpha, stopping_diff=tol)
+    eng.set_option(EXACT, 0)
+    Hs, ss, ds = eng.sparse_code(X, W, H0=H0, alpha=alpha, stopping_diff=tol)
+    return (He, se, de), (Hs, ss, ds)
+
+
+@pytest.mark.parametrize("d,r,b", [(64, 16, 500), (200, 64, 3000), (128, 100, 1111), (96, 256, 2048)])
+def test_screen_agrees_with_full_test(eng, d, r, b):
+    import torch
+    g = torch.Generator(device=eng.device).manual_seed(d + r)
+    X = torch.rand(d, b, device=eng.device, generator=g)
+    W = torch.rand(d, r, device=eng.device, generator=g)
+    W = W / torch.clamp(torch.linalg.norm(W, dim=0), min=1.0)
+    H0 = torch.rand(r, b, device=eng.device, generator=g)
+    (He, se, de), (Hs, ss, ds) = both(eng, X, W, H0, 0.01)
+    assert ss == se
+    assert torch.equal(He, Hs)                 # same kernels' arithmetic on the code either way
+    # every value the screen reports is a valid bound of the exact dist on the continuing side
+    for i in range(ss - 1):
+        assert ds[i] <= de[i] * (1 + 1e-3)
+    # thresholds hugging an actual dist value: just below (loop goes on) and just above (loop ends)
+    k = min(4, se - 1)
+    for tol in (de[k] * 0.97, de[k] * 1.03):
+        (He2, se2, _), (Hs2, ss2, _) = both(eng, X, W, H0, float(tol))
+        ends = [i for i, v in enumerate(de) if not v > tol]      # dist is not monotone in the sweep index
+        assert se2 == (ends[0] + 1 if ends else len(de))
+        assert ss2 == se2
+        assert torch.equal(He2, Hs2)
+
+
+def test_screen_early_stop_and_zero_code(eng):
+    import torch
+    g = torch.Generator(device=eng.device).manual_seed(5)
+    d, r, b = 64, 16, 400
+    X = torch.rand(d, b, device=eng.device, generator=g)
+    W = torch.rand(d, r, device=eng.device, generator=g)
+    W = W / torch.linalg.norm(W, dim=0)
+    # start at a (near) fixed point: the loop must end after the first sweep, like the full test
+    Hc, _, _ = eng.sparse_code(X, W, H0=torch.rand(r, b, device=eng.device, generator=g),
+                               sub_iter=60, stopping_diff=-1.0)
+    (He, se, _), (Hs, ss, _) = both(eng, X, W, Hc, 0.01)
+    assert se == ss == 1 and torch.equal(He, Hs)
+    # all-zero start with X = 0: H stays 0, dist = 0/0 -> the reference's loop ends after one sweep
+    Z = torch.zeros(d, b, device=eng.device)
+    (He, se, _), (Hs, ss, _) = both(eng, Z, W, torch.zeros(r, b, device=eng.device), 0.01)
+    assert se == ss == 1 and float(Hs.abs().max()) == 0.0
+
+
+def test_host_decisions_match_when_screen_is_off(eng):
+    import torch
+    g = torch.Generator(device=eng.device).manual_seed(6)
+    d, r, b = 100, 32, 700
+    X = torch.rand(d, b, device=eng.device, generator=g)
+    W = torch.rand(d, r, device=eng.device, generator=g)
+    H0 = torch.rand(r, b, device=eng.device, generator=g)
+    eng.set_option(SCREEN, 0)
+    Hh, sh, _ = eng.sparse_code(X, W, H0=H0, stopping_diff=0.02)
+    eng.set_option(SCREEN, 1)
+    Hs, ss, _ = eng.sparse_code(X, W, H0=H0, stopping_diff=0.02)
+    assert sh == ss and relerr(host(Hs), host(Hh)) == 0.0
