@@ -121,14 +121,50 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void sweep_tile_kernel(
         if (*sc.flag != 0) return;         // an earlier sweep's test ended the loop (grid-uniform)
     }
 
-    // ---- stage Gm into LDS (whole workgroup) ----
-    for (int K = 0; K < NB; ++K) {
-        const int jend = HALF ? (K + 1) : NB;
-        for (int e = tid; e < jend * 256; e += TILE_WAVES * 64) {
-            const int J = e >> 8, i = (e >> 4) & 15, j = e & 15;
-            const int row = 16 * K + i, col = 16 * J + j;
-            const float v = (row < r && col < r) ? Gm[(size_t)row * r + col] : 0.f;
-            Gs[blk_index<NB, HALF>(K, J) * 256 + blk_off(i, j)] = v;
+    // ---- stage Gm into LDS (whole workgroup): one float4 (4 consecutive columns of one row of a
+    // block) per item, all of a thread's loads in flight together ----
+    {
+        constexpr int ITEMS = NBLK * 64;
+        constexpr int PER_THREAD = (ITEMS + TILE_WAVES * 64 - 1) / (TILE_WAVES * 64);
+        const bool vec_ok = ((r & 3) == 0) && ((((uintptr_t)Gm) & 15) == 0);
+        float4 stage[PER_THREAD];
+#pragma unroll
+        for (int it = 0; it < PER_THREAD; ++it) {
+            const int item = tid + it * TILE_WAVES * 64;
+            const int n = min(item >> 6, NBLK - 1);
+            int K, J;
+            if (HALF) {
+                K = (int)((sqrtf(8.0f * (float)n + 1.0f) - 1.0f) * 0.5f);
+                while (K * (K + 1) / 2 > n) --K;
+                while ((K + 1) * (K + 2) / 2 <= n) ++K;
+                J = n - K * (K + 1) / 2;
+            } else {
+                K = n / NB;
+                J = n - K * NB;
+            }
+            const int q = item & 63;
+            const int row = 16 * K + (q >> 2), col = 16 * J + 4 * (q & 3);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < r) {
+                const float* src = Gm + (size_t)row * r + col;
+                if (vec_ok && col + 3 < r) {
+                    v = *reinterpret_cast<const float4*>(src);
+                } else {
+                    if (col + 0 < r) v.x = src[0];
+                    if (col + 1 < r) v.y = src[1];
+                    if (col + 2 < r) v.z = src[2];
+                    if (col + 3 < r) v.w = src[3];
+                }
+            }
+            stage[it] = v;
+        }
+#pragma unroll
+        for (int it = 0; it < PER_THREAD; ++it) {
+            const int item = tid + it * TILE_WAVES * 64;
+            if (item < ITEMS) {
+                const int q = item & 63, i = q >> 2;
+                *reinterpret_cast<float4*>(Gs + (item >> 6) * 256 + i * 16 + 4 * ((q & 3) ^ swz(i))) = stage[it];
+            }
         }
     }
     for (int k = tid; k < 16 * NB; k += TILE_WAVES * 64) {
@@ -157,6 +193,17 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void sweep_tile_kernel(
     const int col = (blockIdx.x * TILE_WAVES + wave) * 16 + c;
     const bool cvalid = col < b;
     const int sw_c = swz(c);               // swizzle of row c (c doubles as the A-operand row index)
+
+    // The four waves that share a SIMD run the same program; left alone they move in lockstep
+    // (all in the MFMA phase, then all in the VALU phase) and the matrix pipe idles half the time.
+    // Distinct static priorities make the arbiter serve them one after the other, so one wave's
+    // row updates run under the others' MFMAs.
+    {
+        const int rank_in_simd = __builtin_amdgcn_readfirstlane(wave) >> 2;
+        if (rank_in_simd == 0) __builtin_amdgcn_s_setprio(3);
+        else if (rank_in_simd == 1) __builtin_amdgcn_s_setprio(2);
+        else if (rank_in_simd == 2) __builtin_amdgcn_s_setprio(1);
+    }
 
     // H and Cm go through buffer descriptors: byte address = (per-lane voffset) + (wave-uniform
     // soffset = row offset * b), no per-access address registers, and the hardware range check
