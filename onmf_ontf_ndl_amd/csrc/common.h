@@ -93,6 +93,12 @@ struct ScreenDev {
 
 // One Gauss-Seidel sweep over all rows: Hout = sweep(Hin).  stats (device, 2 doubles per
 // workgroup) receives sum((Hout-Hin)^2) and sum(Hin^2) partials; *n_groups = number of pairs.
+int launch_sweep_tile_ct1(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm, const float* Hin,
+                          float* Hout, float alpha, float damp, int exact_cd, double* stats,
+                          int* n_groups, hipStream_t s, const ScreenDev* screen);
+int launch_sweep_tile_ct2(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm, const float* Hin,
+                          float* Hout, float alpha, float damp, int exact_cd, double* stats,
+                          int* n_groups, hipStream_t s, const ScreenDev* screen);
 int launch_sweep(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm, const float* Hin,
                  float* Hout, float alpha, float damp, int exact_cd, double* stats, int* n_groups,
                  hipStream_t s, const ScreenDev* screen = nullptr);

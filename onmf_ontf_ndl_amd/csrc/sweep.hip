@@ -51,366 +51,6 @@ __global__ __launch_bounds__(64) void sweep_column_kernel(int r, int b, const fl
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Tile kernel: blocked Gauss-Seidel on the matrix cores.
-//
-// A wave owns 16 columns of H.  Rows are cut into NB blocks of 16.  For block K the products
-//     R = Gm[K, :] . H          (16 x r times r x 16, v_mfma_f32_16x16x4_f32, exact fp32)
-// use the current H (blocks < K already updated this sweep), then the 16 rows of the block are
-// updated in order on the VALU with the in-block corrections  Gm[k, j] * (h_j_new - h_j_old), j < k.
-//
-// Register layout = the MFMA's own: lane l holds column (l & 15); lane group g = l >> 4 holds rows
-// 16J + 4g + t (t = 0..3) of every block J, both for H (the B operand, k index = g) and for the
-// accumulator R (row 4g + t).  H and Cm stay in registers for the whole sweep.
-//
-// LDS holds Gm as 16x16 blocks (1 KB each), XOR-swizzled so that the A-operand read of block (K,J)
-// - one ds_read_b128 per lane: row (l & 15), columns 4g..4g+3 - is conflict-free.  When all NB*NB
-// blocks do not fit (r = 256), only blocks J <= K are stored and block (K,J), J > K, is read
-// transposed from block (J,K) (Gm is symmetric).  A second set of NB blocks holds the strictly
-// lower triangles of the diagonal blocks for the in-block corrections.
-//
-// In-block update, per quad Q of 4 consecutive rows (they live in lane group Q): the owner group
-// runs its 4 rows in order; the 4 deltas are then broadcast to the other groups (ds_bpermute) and
-// pushed into the accumulators of the rows that come later in the block.
-// ---------------------------------------------------------------------------------------------
-constexpr int TILE_WAVES = 16;
-
-__device__ __forceinline__ int swz(int row) { return (-(row >> 2)) & 3; }   // column-quad XOR per row
-
-// dword offset of element (i, j) inside one swizzled 16x16 block
-__device__ __forceinline__ int blk_off(int i, int j) { return i * 16 + 4 * ((j >> 2) ^ swz(i)) + (j & 3); }
-
-template <int NB, bool HALF>
-__device__ __forceinline__ int blk_index(int K, int J) {
-    return HALF ? (K * (K + 1) / 2 + J) : (K * NB + J);
-}
-
-// sum over the 16 lanes of a DPP row (lanes 16g..16g+15); the total lands in lane 16g+15
-__device__ __forceinline__ float row_sum16(float x) {
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x111, 0xf, 0xf, true));
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x112, 0xf, 0xf, true));
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x114, 0xf, 0xf, true));
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x118, 0xf, 0xf, true));
-    return x;
-}
-
-// PROBE = true adds what the stopping test needs without a second pass over H (see screen.hip):
-//   * P = U^T (H_new - H_old) for 16 unit probe vectors U (4 extra MFMAs per block) and, per probe,
-//     sum_c P[p][c]^2  -> a rigorous lower bound of sigma_max(H_new - H_old)^2;
-//   * y = H_new (H_new^T v) for a positive vector v -> Collatz-Wielandt upper bound of
-//     sigma_max(H_new)^2 (H H^T is entrywise nonnegative), used by the NEXT sweep's test;
-// (The power step that refreshes the probe subspace runs on a sample of the columns in its own
-// small kernel, screen.hip.)
-template <int NB, bool HALF, bool PROBE>
-__global__ __launch_bounds__(TILE_WAVES * 64) void sweep_tile_kernel(
-    int r, int b, const float* __restrict__ Gm, const float* __restrict__ Cm,
-    const float* __restrict__ Hin, float* __restrict__ Hout, float alpha, float rdamp, int exact_cd,
-    double* __restrict__ stats, ScreenDev sc) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int NBLK = HALF ? NB * (NB + 1) / 2 : NB * NB;
-    float* Gs = lds;                       // NBLK swizzled 16x16 blocks of Gm
-    float* steps = lds + NBLK * 256;       // 16*NB step sizes (0 for padded rows)
-    float* Us = steps + 16 * NB;           // PROBE: NB swizzled blocks of U^T
-    float* vs = Us + NB * 256;             // PROBE: v
-    float* ywg = vs + 16 * NB;             // PROBE: workgroup partial of y
-    float* p2wg = ywg + 16 * NB;           // PROBE: workgroup partial of the 16 probe energies
-    double* sumwg = reinterpret_cast<double*>(p2wg + 16);   // PROBE: workgroup partial of the two sums
-
-    const int tid = threadIdx.x;
-    if (PROBE) {
-        if (*sc.flag != 0) return;         // an earlier sweep's test ended the loop (grid-uniform)
-    }
-
-    // ---- stage Gm into LDS (whole workgroup): one float4 (4 consecutive columns of one row of a
-    // block) per item, all of a thread's loads in flight together ----
-    {
-        constexpr int ITEMS = NBLK * 64;
-        constexpr int PER_THREAD = (ITEMS + TILE_WAVES * 64 - 1) / (TILE_WAVES * 64);
-        const bool vec_ok = ((r & 3) == 0) && ((((uintptr_t)Gm) & 15) == 0);
-        float4 stage[PER_THREAD];
-#pragma unroll
-        for (int it = 0; it < PER_THREAD; ++it) {
-            const int item = tid + it * TILE_WAVES * 64;
-            const int n = min(item >> 6, NBLK - 1);
-            int K, J;
-            if (HALF) {
-                K = (int)((sqrtf(8.0f * (float)n + 1.0f) - 1.0f) * 0.5f);
-                while (K * (K + 1) / 2 > n) --K;
-                while ((K + 1) * (K + 2) / 2 <= n) ++K;
-                J = n - K * (K + 1) / 2;
-            } else {
-                K = n / NB;
-                J = n - K * NB;
-            }
-            const int q = item & 63;
-            const int row = 16 * K + (q >> 2), col = 16 * J + 4 * (q & 3);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < r) {
-                const float* src = Gm + (size_t)row * r + col;
-                if (vec_ok && col + 3 < r) {
-                    v = *reinterpret_cast<const float4*>(src);
-                } else {
-                    if (col + 0 < r) v.x = src[0];
-                    if (col + 1 < r) v.y = src[1];
-                    if (col + 2 < r) v.z = src[2];
-                    if (col + 3 < r) v.w = src[3];
-                }
-            }
-            stage[it] = v;
-        }
-#pragma unroll
-        for (int it = 0; it < PER_THREAD; ++it) {
-            const int item = tid + it * TILE_WAVES * 64;
-            if (item < ITEMS) {
-                const int q = item & 63, i = q >> 2;
-                *reinterpret_cast<float4*>(Gs + (item >> 6) * 256 + i * 16 + 4 * ((q & 3) ^ swz(i))) = stage[it];
-            }
-        }
-    }
-    for (int k = tid; k < 16 * NB; k += TILE_WAVES * 64) {
-        float st = 0.f;
-        if (k < r) {
-            const float gkk = Gm[(size_t)k * r + k];
-            st = exact_cd ? (gkk > 0.f ? 1.0f / gkk : 0.f) : rdamp / (gkk + 1.0f);
-        }
-        steps[k] = st;
-        if (PROBE) {
-            vs[k] = sc.v[k];
-            ywg[k] = 0.f;
-        }
-    }
-    if (PROBE) {
-        for (int e = tid; e < NB * 256; e += TILE_WAVES * 64) Us[e] = sc.ublk[e];
-        if (tid < 16) p2wg[tid] = 0.f;
-        if (tid < 2) sumwg[tid] = 0.0;
-    }
-    __syncthreads();
-
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int c = lane & 15;
-    const int g = lane >> 4;
-    const int col = (blockIdx.x * TILE_WAVES + wave) * 16 + c;
-    const bool cvalid = col < b;
-    const int sw_c = swz(c);               // swizzle of row c (c doubles as the A-operand row index)
-
-    // The four waves that share a SIMD run the same program; left alone they move in lockstep
-    // (all in the MFMA phase, then all in the VALU phase) and the matrix pipe idles half the time.
-    // Distinct static priorities make the arbiter serve them one after the other, so one wave's
-    // row updates run under the others' MFMAs.
-    {
-        const int rank_in_simd = __builtin_amdgcn_readfirstlane(wave) >> 2;
-        if (rank_in_simd == 0) __builtin_amdgcn_s_setprio(3);
-        else if (rank_in_simd == 1) __builtin_amdgcn_s_setprio(2);
-        else if (rank_in_simd == 2) __builtin_amdgcn_s_setprio(1);
-    }
-
-    // H and Cm go through buffer descriptors: byte address = (per-lane voffset) + (wave-uniform
-    // soffset = row offset * b), no per-access address registers, and the hardware range check
-    // returns 0 for rows >= r (their offset is past r*b floats) and drops such stores.  Columns
-    // >= b are clamped for loads (value masked) and pushed out of range for stores.
-    // The host guarantees r * b * 4 < 2^31.
-    const unsigned nbytes = (unsigned)r * (unsigned)b * 4u;
-    const auto rs_h = __builtin_amdgcn_make_buffer_rsrc((void*)Hin, 0, nbytes, 0x00020000);
-    const auto rs_c = __builtin_amdgcn_make_buffer_rsrc((void*)Cm, 0, nbytes, 0x00020000);
-    const auto rs_o = __builtin_amdgcn_make_buffer_rsrc((void*)Hout, 0, nbytes, 0x00020000);
-    const int voff = (4 * g * b + min(col, b - 1)) * 4;
-    const int voff_st = cvalid ? voff : (int)0x80000000;
-    float h[NB][4];
-    float hsum = 0.f, dsum = 0.f;
-#pragma unroll
-    for (int J = 0; J < NB; ++J) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_h, voff, (16 * J + t) * b * 4, 0));
-            v = cvalid ? v : 0.f;
-            h[J][t] = v;
-            hsum = fmaf(v, v, hsum);
-        }
-    }
-    f32x4 pacc = {0.f, 0.f, 0.f, 0.f};
-
-#pragma unroll
-    for (int K = 0; K < NB; ++K) {
-        // keep the compiler from hoisting later blocks' LDS reads above this point (register budget)
-        __builtin_amdgcn_sched_barrier(0);
-        // Cm is touched once per sweep: fetch this block's four values now, use them after the MFMAs
-        // (row offsets are recomputed from an opaque copy of b per block: kept as common
-        // subexpressions, the 4*NB scalar offsets would occupy most of the scalar register file)
-        int bk = b;
-        asm volatile("" : "+s"(bk));
-        float cmk[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-            cmk[t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_c, voff, (16 * K + t) * bk * 4, 0));
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int J = 0; J < NB; ++J) {
-            // bound how many A-operand reads are in flight at once (register budget: 128 per lane)
-            if (NB > 8 && J > 0 && (J % 6) == 0) __builtin_amdgcn_sched_barrier(0);
-            float a0, a1, a2, a3;
-            if (!HALF || J <= K) {
-                const float4 a = *reinterpret_cast<const float4*>(
-                    Gs + blk_index<NB, HALF>(K, J) * 256 + c * 16 + 4 * (g ^ sw_c));
-                a0 = a.x; a1 = a.y; a2 = a.z; a3 = a.w;
-            } else {
-                // Gm[16K+c][16J+4g+t] = Gm[16J+4g+t][16K+c]: rows 4g+t of block (J,K), column c
-                const float* blk = Gs + blk_index<NB, HALF>(J, K) * 256 + 64 * g +
-                                   4 * ((c >> 2) ^ ((-g) & 3)) + (c & 3);
-                a0 = blk[0]; a1 = blk[16]; a2 = blk[32]; a3 = blk[48];
-            }
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, h[J][0], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, h[J][1], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, h[J][2], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, h[J][3], acc1, 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        float acc[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = acc0[t] + acc1[t];
-        const float4 st4 = *reinterpret_cast<const float4*>(steps + 16 * K + 4 * g);
-        // columns past b hold zeros and must stay zero (their stores are dropped, but their
-        // deltas would pollute the statistics): step 0
-        const float st[4] = {cvalid ? st4.x : 0.f, cvalid ? st4.y : 0.f, cvalid ? st4.z : 0.f,
-                             cvalid ? st4.w : 0.f};
-        float hold4[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) hold4[t] = h[K][t];
-
-#pragma unroll
-        for (int Q = 0; Q < 4; ++Q) {
-            const bool own = (g == Q);
-            // Gq[t][tj] = Gm[16K+4g+t][16K+4Q+tj] from the diagonal block (rows 4g+t, column quad Q)
-            float Gq[4][4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const float4 v = *reinterpret_cast<const float4*>(
-                    Gs + blk_index<NB, HALF>(K, K) * 256 + (4 * g + t) * 16 + 4 * (Q ^ ((-g) & 3)));
-                Gq[t][0] = v.x; Gq[t][1] = v.y; Gq[t][2] = v.z; Gq[t][3] = v.w;
-            }
-            float dq[4];
-#pragma unroll
-            for (int tj = 0; tj < 4; ++tj) {
-                const float hold = h[K][tj];
-                const float grad = acc[tj] - cmk[tj] + alpha;
-                const float hnew = fmaxf(hold - grad * st[tj], 0.f);
-                const float dl = own ? (hnew - hold) : 0.f;
-                h[K][tj] = own ? hnew : hold;
-                dsum = fmaf(dl, dl, dsum);
-                dq[tj] = dl;
-                // rows of this quad that come later (owner lanes only: elsewhere dl == 0)
-#pragma unroll
-                for (int t = tj + 1; t < 4; ++t) acc[t] = fmaf(Gq[t][tj], dl, acc[t]);
-            }
-            if (Q < 3) {
-                // push the four deltas into the rows of the lane groups that come later in the block
-                const bool later = (g > Q);
-#pragma unroll
-                for (int tj = 0; tj < 4; ++tj) {
-                    const float all = __shfl(dq[tj], 16 * Q + c, 64);
-                    const float other = later ? all : 0.f;
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) acc[t] = fmaf(Gq[t][tj], other, acc[t]);
-                }
-            }
-            asm volatile("" : "+v"(dsum));     // keep the running sum current (no deferred chain)
-        }
-        if (PROBE) {
-            const float4 u4 = *reinterpret_cast<const float4*>(Us + K * 256 + c * 16 + 4 * (g ^ sw_c));
-            pacc = __builtin_amdgcn_mfma_f32_16x16x4f32(u4.x, h[K][0] - hold4[0], pacc, 0, 0, 0);
-            pacc = __builtin_amdgcn_mfma_f32_16x16x4f32(u4.y, h[K][1] - hold4[1], pacc, 0, 0, 0);
-            pacc = __builtin_amdgcn_mfma_f32_16x16x4f32(u4.z, h[K][2] - hold4[2], pacc, 0, 0, 0);
-            pacc = __builtin_amdgcn_mfma_f32_16x16x4f32(u4.w, h[K][3] - hold4[3], pacc, 0, 0, 0);
-        }
-    }
-
-#pragma unroll
-    for (int J = 0; J < NB; ++J) {
-        int bj = b;
-        asm volatile("" : "+s"(bj));
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(h[J][t]), rs_o, voff_st,
-                                                  (16 * J + t) * bj * 4, 0);
-    }
-    double ds = dsum, hh = hsum;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        ds += __shfl_xor(ds, off);
-        hh += __shfl_xor(hh, off);
-    }
-    if (lane == 0) {
-        const int slot = blockIdx.x * TILE_WAVES + wave;
-        stats[2 * slot + 0] = ds;
-        stats[2 * slot + 1] = hh;
-        if (PROBE) {
-            atomicAdd(&sumwg[0], ds);
-            atomicAdd(&sumwg[1], hh);
-        }
-    }
-
-    if (PROBE) {
-        __builtin_amdgcn_sched_barrier(0);
-        // energy of each probe's projection over this wave's columns: lane (c,g) reg t = probe 4g+t
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const float e = row_sum16(pacc[t] * pacc[t]);
-            if (c == 15) atomicAdd(&p2wg[4 * g + t], e);
-        }
-        // Collatz-Wielandt: ph[c] = sum_rows v[row] * H_new[row][c], then y[row] += H_new[row][c] * ph[c]
-        float ph = 0.f;
-#pragma unroll
-        for (int J = 0; J < NB; ++J) {
-            if ((J & 3) == 0) __builtin_amdgcn_sched_barrier(0);
-            const float4 v4 = *reinterpret_cast<const float4*>(vs + 16 * J + 4 * g);
-            ph = fmaf(v4.x, h[J][0], ph);
-            ph = fmaf(v4.y, h[J][1], ph);
-            ph = fmaf(v4.z, h[J][2], ph);
-            ph = fmaf(v4.w, h[J][3], ph);
-        }
-        ph += __shfl_xor(ph, 16);
-        ph += __shfl_xor(ph, 32);
-#pragma unroll
-        for (int J = 0; J < NB; ++J) {
-            __builtin_amdgcn_sched_barrier(0);     // one block at a time: bounded register use
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const float e = row_sum16(h[J][t] * ph);
-                if (c == 15) atomicAdd(&ywg[16 * J + 4 * g + t], e);
-            }
-        }
-        __syncthreads();
-        // one set of global atomics per workgroup, spread over replicas to keep contention low
-        const int rep = blockIdx.x % SCREEN_REPL;
-        for (int k = tid; k < 16 * NB; k += TILE_WAVES * 64) atomicAdd(&sc.yacc[rep * 256 + k], ywg[k]);
-        if (tid < 16) atomicAdd(&sc.p2acc[rep * 16 + tid], p2wg[tid]);
-        if (tid < 2) atomicAdd(&sc.sums[rep * 2 + tid], sumwg[tid]);
-    }
-}
-
-template <int NB, bool HALF, bool PROBE>
-int run_tile(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm, const float* Hin, float* Hout,
-             float alpha, float damp, int exact_cd, double* stats, int* n_groups, const ScreenDev& sc,
-             hipStream_t s) {
-    constexpr int NBLK = HALF ? NB * (NB + 1) / 2 : NB * NB;
-    constexpr size_t lds = sizeof(float) * ((size_t)NBLK * 256 + NB * 16 +
-                                            (PROBE ? (NB * 256 + 2 * NB * 16 + 16 + 4) : 0));
-    static_assert(lds <= 160 * 1024, "Gm blocks do not fit the LDS");
-    static bool attr_done = false;
-    if (!attr_done) {
-        HIP_TRY(c, hipFuncSetAttribute((const void*)sweep_tile_kernel<NB, HALF, PROBE>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
-    }
-    const int cols_per_wg = TILE_WAVES * 16;
-    const int wgs = (b + cols_per_wg - 1) / cols_per_wg;
-    *n_groups = wgs * TILE_WAVES;
-    hipLaunchKernelGGL((sweep_tile_kernel<NB, HALF, PROBE>), dim3(wgs), dim3(TILE_WAVES * 64), lds, s, r, b,
-                       Gm, Cm, Hin, Hout, alpha, 1.0f / damp, exact_cd, stats, sc);
-    HIP_TRY(c, hipGetLastError());
-    return ONMF_OK;
-}
-
 }  // namespace
 
 static int launch_sweep_column(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm,
@@ -440,38 +80,17 @@ int launch_sweep(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm, co
                  float* Hout, float alpha, float damp, int exact_cd, double* stats, int* n_groups,
                  hipStream_t s, const ScreenDev* screen) {
     const int nb = (r + 15) / 16;
-    const bool want_tile = sweep_tile_covers(r, b) && (c->sweep_kernel == 2 || c->sweep_kernel == 0);
+    const bool want_tile = sweep_tile_covers(r, b) && c->sweep_kernel != 1;
     if (!want_tile) {
-        if (c->sweep_kernel == 2)
+        if (c->sweep_kernel >= 2)
             return onmf_fail(c, ONMF_ERR_ARG, "sweep: the tile kernel covers r <= 256 (r=%d)", r);
         if (screen) return onmf_fail(c, ONMF_ERR_ARG, "sweep: probes need the tile kernel");
         return launch_sweep_column(c, r, b, Gm, Cm, Hin, Hout, alpha, damp, exact_cd, stats, n_groups, s);
     }
-    ScreenDev none = {};
-#define TILE_CASE(NBV, HALFV)                                                                          \
-    case NBV:                                                                                          \
-        return screen ? run_tile<NBV, HALFV, true>(c, r, b, Gm, Cm, Hin, Hout, alpha, damp, exact_cd,   \
-                                                   stats, n_groups, *screen, s)                        \
-                      : run_tile<NBV, HALFV, false>(c, r, b, Gm, Cm, Hin, Hout, alpha, damp, exact_cd,  \
-                                                    stats, n_groups, none, s)
-    switch (nb) {
-        TILE_CASE(1, false);
-        TILE_CASE(2, false);
-        TILE_CASE(3, false);
-        TILE_CASE(4, false);
-        TILE_CASE(5, false);
-        TILE_CASE(6, false);
-        TILE_CASE(7, false);
-        TILE_CASE(8, false);
-        TILE_CASE(9, false);
-        TILE_CASE(10, false);
-        TILE_CASE(11, false);
-        TILE_CASE(12, true);
-        TILE_CASE(13, true);
-        TILE_CASE(14, true);
-        TILE_CASE(15, true);
-        TILE_CASE(16, true);
-    }
-#undef TILE_CASE
-    return onmf_fail(c, ONMF_ERR_ARG, "sweep: unsupported r=%d", r);
+    // 2 column tiles per wave unless asked otherwise (option values 3 / 4 pin 1 / 2)
+    const bool two = c->sweep_kernel != 3;
+    return two ? launch_sweep_tile_ct2(c, r, b, Gm, Cm, Hin, Hout, alpha, damp, exact_cd, stats, n_groups, s,
+                                       screen)
+               : launch_sweep_tile_ct1(c, r, b, Gm, Cm, Hin, Hout, alpha, damp, exact_cd, stats, n_groups, s,
+                                       screen);
 }

@@ -14,10 +14,13 @@ def main():
     ap.add_argument("--b", type=int, default=65536)
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--tol", type=float, default=0.0)
+    ap.add_argument("--kernel", type=int, default=0, help="ONMF_OPT_SWEEP_KERNEL value")
     args = ap.parse_args()
     import torch
     from onmf_ontf_ndl_amd.engine import get_engine
     eng = get_engine()
+    from onmf_ontf_ndl_amd import _lib
+    eng.set_option(_lib.OPT_SWEEP_KERNEL, args.kernel)
     g = torch.Generator(device=eng.device).manual_seed(1)
     X = torch.rand(args.d, args.b, device=eng.device, generator=g)
     W = torch.rand(args.d, args.r, device=eng.device, generator=g)
