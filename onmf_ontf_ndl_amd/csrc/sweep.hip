@@ -87,10 +87,10 @@ int launch_sweep(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm, co
         if (screen) return onmf_fail(c, ONMF_ERR_ARG, "sweep: probes need the tile kernel");
         return launch_sweep_column(c, r, b, Gm, Cm, Hin, Hout, alpha, damp, exact_cd, stats, n_groups, s);
     }
-    // 2 column tiles per wave unless asked otherwise (option values 3 / 4 pin 1 / 2)
-    const bool two = c->sweep_kernel != 3;
-    return two ? launch_sweep_tile_ct2(c, r, b, Gm, Cm, Hin, Hout, alpha, damp, exact_cd, stats, n_groups, s,
-                                       screen)
-               : launch_sweep_tile_ct1(c, r, b, Gm, Cm, Hin, Hout, alpha, damp, exact_cd, stats, n_groups, s,
-                                       screen);
+    // column tiles per wave: 1 unless option value 4 asks for 2
+    if (c->sweep_kernel == 4)
+        return launch_sweep_tile_ct2(c, r, b, Gm, Cm, Hin, Hout, alpha, damp, exact_cd, stats, n_groups, s,
+                                     screen);
+    return launch_sweep_tile_ct1(c, r, b, Gm, Cm, Hin, Hout, alpha, damp, exact_cd, stats, n_groups, s,
+                                 screen);
 }

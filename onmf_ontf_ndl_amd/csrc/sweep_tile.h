@@ -154,16 +154,6 @@ __global__ __launch_bounds__(1024 / CT) void sweep_tile_kernel(
     const int g = lane >> 4;
     const int sw_c = swz(c);               // swizzle of row c (c doubles as the A-operand row index)
 
-    // The waves that share a SIMD run the same program; left alone they move in lockstep (all in
-    // the MFMA phase, then all in the VALU phase).  Distinct static priorities make the arbiter
-    // serve them one after the other, so one wave's row updates run under the others' MFMAs.
-    {
-        const int rank_in_simd = __builtin_amdgcn_readfirstlane(wave) >> 2;
-        if (rank_in_simd == 0) __builtin_amdgcn_s_setprio(3);
-        else if (rank_in_simd == 1) __builtin_amdgcn_s_setprio(2);
-        else if (rank_in_simd == 2) __builtin_amdgcn_s_setprio(1);
-    }
-
     // H and Cm go through buffer descriptors: byte address = (per-lane voffset) + (wave-uniform
     // soffset = row offset * b), no per-access address registers, and the hardware range check
     // returns 0 for rows >= r (their offset is past r*b floats) and drops such stores.  Columns
@@ -325,6 +315,7 @@ __global__ __launch_bounds__(1024 / CT) void sweep_tile_kernel(
             }
         }
         asm volatile("" : "+v"(dsum));     // keep the running sum current (no deferred chain)
+        __builtin_amdgcn_s_setprio(0);
         // rows of block K are final: store them now, under the remaining blocks' arithmetic
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
