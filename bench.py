@@ -82,6 +82,8 @@ def main():
     ap.add_argument("--sync-every", type=int, default=4, help="steps between (A,B,W) all-reduces at N>1")
     ap.add_argument("--batches", type=int, default=3, help="distinct resident batches cycled through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
+                    help="library option (ONMF_OPT_* number = value), for experiments")
     ap.add_argument("--cpu-cols", type=int, default=0, help="columns of the CPU-baseline sample (0 = auto)")
     args = ap.parse_args()
 
@@ -99,6 +101,9 @@ def main():
         raise SystemExit("bench.py needs a GPU (there is no CPU path)")
     torch.cuda.set_device(local)
     eng = get_engine(torch.device("cuda", local))
+    for kv in args.opt:
+        key, value = kv.split("=")
+        eng.set_option(int(key), int(value))
     d, r, b = WORKLOADS[args.workload]
 
     gen = torch.Generator(device=eng.device).manual_seed(1234 + rank)

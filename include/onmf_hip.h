@@ -128,19 +128,23 @@ double onmf_host_lambda_max(const float* S_host, int n);
  *   ONMF_OPT_EXACT_STOP    != 0: always evaluate the spectral-norm stopping test in full (Gram
  *                          matrices + eigenvalues) instead of deciding by norm bounds when those
  *                          are conclusive; dist_trace then holds every dist value.
- *   ONMF_OPT_SWEEP_KERNEL  0 = pick by shape, 1 = column-per-lane kernel, 2 = MFMA tile kernel.
+ *   ONMF_OPT_SWEEP_KERNEL  0 = pick by shape, 1 = column-per-lane kernel, 2 = MFMA tile kernel
+ *                          (3 / 4: tile kernel pinned to 1 / 2 column tiles of 16 per wave).
  *   ONMF_OPT_OVERLAP_DICT  != 0 (default): onmf_step runs the dictionary pass on a second stream
  *                          beside the code solve when no output aliases an input.
  *   ONMF_OPT_SCREEN_STOP   != 0 (default): decide the stopping test on the device from rigorous
  *                          bounds that the sweep kernel produces as by-products, all sweeps
  *                          enqueued without host round trips; the full test runs only where the
  *                          bounds straddle stopping_diff.  0: one host decision per sweep.
+ *   ONMF_OPT_DICT_KERNEL   0 = pick by shape, 1 = cooperating one-wave workgroups (any d <= 16384),
+ *                          2 = one workgroup (d <= 4096).
  */
 #define ONMF_OPT_PROFILE 1
 #define ONMF_OPT_EXACT_STOP 2
 #define ONMF_OPT_SWEEP_KERNEL 3
 #define ONMF_OPT_OVERLAP_DICT 4
 #define ONMF_OPT_SCREEN_STOP 5
+#define ONMF_OPT_DICT_KERNEL 6
 int onmf_set_option(onmf_ctx* ctx, int key, int value);
 /* Summed device time (ms) and number of sweep-kernel launches since the previous call. */
 int onmf_get_profile(onmf_ctx* ctx, double* sweep_ms, int* sweep_launches);

@@ -179,7 +179,7 @@ int onmf_destroy(onmf_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     DevBuf* bufs[] = {&c->slab, &c->cm, &c->gram, &c->hbuf[0], &c->hbuf[1], &c->stats, &c->small,
-                      &c->qt, &c->sync, &c->idx, &c->dbuf, &c->slab_side, &c->screen};
+                      &c->qt, &c->sync, &c->idx, &c->dbuf, &c->slab_side, &c->screen, &c->ddelta};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (c->pinned) (void)hipHostFree(c->pinned);
@@ -201,6 +201,7 @@ int onmf_set_option(onmf_ctx* c, int key, int value) {
         case ONMF_OPT_SWEEP_KERNEL: c->sweep_kernel = value; return ONMF_OK;
         case ONMF_OPT_OVERLAP_DICT: c->overlap_dict = value; return ONMF_OK;
         case ONMF_OPT_SCREEN_STOP: c->screen_stop = value; return ONMF_OK;
+        case ONMF_OPT_DICT_KERNEL: c->dict_kernel = value; return ONMF_OK;
         default: return onmf_fail(c, ONMF_ERR_ARG, "onmf_set_option: unknown key %d", key);
     }
 }
@@ -443,7 +444,7 @@ static int aggregate_impl(onmf_ctx* c, int d, int r, int b, const float* X, int 
 
 static int dict_check(onmf_ctx* c, int r, int d, hipStream_t s) {
     const int nwg = (d + 63) / 64;
-    if (nwg <= 1) return ONMF_OK;
+    if (nwg <= 1 || !c->dict_coop_last) return ONMF_OK;
     const size_t off = (size_t)r * nwg * sizeof(unsigned long long);
     ONMF_TRY(onmf_reserve_pinned(c, 64));
     HIP_TRY(c, hipMemcpyAsync(c->pinned, (char*)c->sync.p + off, sizeof(int), hipMemcpyDeviceToHost, s));

@@ -10,6 +10,10 @@
 // sequential d-wide reductions.  Each workgroup publishes its partial sum of squares as one
 // 8-byte {tag, value} word with an agent-scope store, and every workgroup sums all words in the
 // same fixed order, so all of them scale by the bitwise-identical norm.
+//
+// That kernel pays one cross-workgroup exchange per atom (microseconds each).  For d <= 4096 a
+// second kernel keeps the whole pass inside ONE workgroup (dict_panel_kernel below), where the
+// norm costs an LDS round and a barrier; it occupies a single CU and is several times faster.
 #include "common.h"
 
 namespace {
@@ -83,6 +87,161 @@ __global__ __launch_bounds__(64) void dict_pass_kernel(int d, int r, int nwg,
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// One-workgroup pass.  Thread t owns rows t, t + 1024, ... (RPT of them).  Atoms are taken in
+// panels of PW.  For a panel starting at atom j0 the thread first brings its PW entries of
+// Q - B up to date from the deltas of all earlier atoms (left-looking: q[n] += delta_k * A[k][j0+n],
+// k < j0; its own deltas read back from `Dt`, stored [atom][row] so that a wave's access is one
+// contiguous line; the entries of A wave-uniform, fetched as 64-byte scalar loads from a copy of A
+// whose rows are padded with zeros to a multiple of 16), then runs the PW atoms in order: the norm
+// is a wave sum, one LDS slot per wave and a barrier; later atoms of the panel take the delta at
+// once.  No state is shared between threads except the norm partials.  W is read and written
+// transposed ([atom][row], contiguous along a wave); the launcher transposes on the way in and out.
+// ---------------------------------------------------------------------------------------------
+struct alignas(64) Row16 {
+    float v[16];
+};
+
+// sum over the wave, returned wave-uniform (DPP row sums, then the four row totals)
+__device__ __forceinline__ float wave_sum_uniform(float x) {
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x111, 0xf, 0xf, true));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x112, 0xf, 0xf, true));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x114, 0xf, 0xf, true));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x118, 0xf, 0xf, true));
+    const int xi = __builtin_bit_cast(int, x);
+    return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 15)) +
+            __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 31))) +
+           (__builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 47)) +
+            __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 63)));
+}
+
+// Ap[k][0..lda) = A[k][0..r) followed by zeros; inv[k] = 1 / (A[k][k] + 1)
+__global__ void dict_pad_kernel(int r, int lda, const float* __restrict__ A, float* __restrict__ Ap,
+                                float* __restrict__ inv) {
+    const int k = blockIdx.x;
+    for (int j = threadIdx.x; j < lda; j += blockDim.x) Ap[(size_t)k * lda + j] = j < r ? A[(size_t)k * r + j] : 0.f;
+    if (threadIdx.x == 0) inv[k] = 1.0f / (A[(size_t)k * r + k] + 1.0f);
+    if (k == 0)
+        for (int j = r + threadIdx.x; j < lda; j += blockDim.x) inv[j] = 0.f;
+}
+
+template <int RPT, int PW>
+__global__ __launch_bounds__(1024) void dict_panel_kernel(int d, int r, int lda,
+                                                          const float* __restrict__ Qt0,
+                                                          const float* __restrict__ Ap,
+                                                          const float* __restrict__ inv_diag,
+                                                          const float* __restrict__ B,
+                                                          const float* __restrict__ Wt,
+                                                          float* __restrict__ WtOut, float* Dt) {
+    static_assert(PW == 16 || PW == 8, "panel width");
+    __shared__ __attribute__((aligned(16))) float part[2][16];   // one slot per wave; unused slots stay 0
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6;
+    if (tid < 32) part[tid >> 4][tid & 15] = 0.f;
+    __syncthreads();
+    int row[RPT];          // clamped: rows past the end compute on a copy of row d-1 and store nothing
+    bool valid[RPT];
+#pragma unroll
+    for (int p = 0; p < RPT; ++p) {
+        const int i = tid + p * (int)blockDim.x;
+        valid[p] = i < d;
+        row[p] = min(i, d - 1);
+    }
+    for (int j0 = 0; j0 < r; j0 += PW) {
+        float q[RPT][PW], w[RPT][PW];
+        // this panel's entries of Q0 - B and of W (atoms past the end: copies of atom r-1, unused)
+#pragma unroll
+        for (int p = 0; p < RPT; ++p) {
+#pragma unroll
+            for (int n = 0; n < PW; ++n) {
+                const int j = min(j0 + n, r - 1);
+                const size_t at = (size_t)j * d + row[p];
+                q[p][n] = Qt0[at] - B[at];
+                w[p][n] = Wt[at];
+            }
+        }
+        // left-looking update from the atoms before the panel; the deltas of the next four atoms
+        // are fetched while the current four are applied
+        float dn[RPT][4];
+        if (j0 > 0) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int p = 0; p < RPT; ++p) dn[p][kk] = Dt[(size_t)kk * d + row[p]];
+        }
+        for (int k = 0; k < j0; k += 4) {
+            float dl[RPT][4];
+            const int kn = min(k + 4, j0 - 4);           // last round: fetches its own group again
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int p = 0; p < RPT; ++p) {
+                    dl[p][kk] = dn[p][kk];
+                    dn[p][kk] = Dt[(size_t)(kn + kk) * d + row[p]];
+                }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                if (PW == 16) {
+                    const Row16 a = *reinterpret_cast<const Row16*>(Ap + (size_t)(k + kk) * lda + j0);
+#pragma unroll
+                    for (int n = 0; n < PW; ++n)
+#pragma unroll
+                        for (int p = 0; p < RPT; ++p) q[p][n] = fmaf(dl[p][kk], a.v[n], q[p][n]);
+                } else {
+                    const float* __restrict__ a = Ap + (size_t)(k + kk) * lda + j0;
+#pragma unroll
+                    for (int n = 0; n < PW; ++n)
+#pragma unroll
+                        for (int p = 0; p < RPT; ++p) q[p][n] = fmaf(dl[p][kk], a[n], q[p][n]);
+                }
+            }
+        }
+        // The panel's atoms in order (padded atoms j >= r run on zeros of Ap: harmless, not stored).
+        // The barrier below orders LDS traffic only: waiting for the global stores of the deltas as
+        // well (what __syncthreads would do) costs a memory round trip per atom.  The row of A for
+        // the next atom is fetched right after the barrier, a whole atom ahead of its use.
+        const Row16 inv16 = *reinterpret_cast<const Row16*>(inv_diag + (j0 & ~15));
+        Row16 acur = *reinterpret_cast<const Row16*>(Ap + (size_t)min(j0, r - 1) * lda + (j0 & ~15));
+#pragma unroll
+        for (int n = 0; n < PW; ++n) {
+            const int j = j0 + n;
+            const float inv = inv16.v[(j0 & 15) + n];
+            float u[RPT];
+            float ss = 0.f;
+#pragma unroll
+            for (int p = 0; p < RPT; ++p) {
+                u[p] = fmaxf(w[p][n] - q[p][n] * inv, 0.f);
+                ss = valid[p] ? fmaf(u[p], u[p], ss) : ss;
+            }
+            const float ws = wave_sum_uniform(ss);
+            if ((tid & 63) == 0) part[n & 1][wave] = ws;
+            __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): the LDS write has landed
+            __builtin_amdgcn_s_barrier();
+            Row16 anext = acur;
+            if (n + 1 < PW)
+                anext = *reinterpret_cast<const Row16*>(Ap + (size_t)min(j + 1, r - 1) * lda + (j0 & ~15));
+            // all 16 slots in one LDS round, summed in a fixed order by every thread
+            const float4* pp = reinterpret_cast<const float4*>(part[n & 1]);
+            const float4 s0 = pp[0], s1 = pp[1], s2 = pp[2], s3 = pp[3];
+            const float total = (((s0.x + s0.y) + (s0.z + s0.w)) + ((s1.x + s1.y) + (s1.z + s1.w))) +
+                                (((s2.x + s2.y) + (s2.z + s2.w)) + ((s3.x + s3.y) + (s3.z + s3.w)));
+            const float scale = 1.0f / fmaxf(1.0f, sqrtf(total));
+#pragma unroll
+            for (int p = 0; p < RPT; ++p) {
+                const float wn = u[p] * scale;
+                const float dv = wn - w[p][n];
+                if (valid[p] && j < r) {
+                    WtOut[(size_t)j * d + row[p]] = wn;
+                    Dt[(size_t)j * d + row[p]] = dv;
+                }
+#pragma unroll
+                for (int m = n + 1; m < PW; ++m) q[p][m] = fmaf(acur.v[(j0 & 15) + m], dv, q[p][m]);
+            }
+            acur = anext;
+        }
+    }
+}
+
 __global__ void zero_u64_kernel(u64* p, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
          i += (size_t)gridDim.x * blockDim.x)
@@ -93,6 +252,42 @@ __global__ void zero_u64_kernel(u64* p, size_t n) {
 
 int launch_dict_pass(onmf_ctx* c, int d, int r, const float* Win, const float* A, const float* B,
                      float* Wout, hipStream_t s) {
+    c->dict_coop_last = false;
+    if ((c->dict_kernel == 2 && d <= 4096) || (c->dict_kernel == 0 && d <= 1024)) {
+        // Qt0[j][i] = sum_k A[k][j] * W[i][k]
+        ONMF_TRY(onmf_reserve(c, c->qt, (size_t)r * d * sizeof(float), "dictionary Qt"));
+        float* Qt = (float*)c->qt.p;
+        ONMF_TRY(launch_gemm(c, /*a_km=*/true, /*b_kn=*/false, r, d, r, A, r, Win, r, 1.f, 0.f, nullptr,
+                             Qt, d, s, &c->slab_side));
+        const int lda = (r + 15) / 16 * 16;
+        ONMF_TRY(onmf_reserve(c, c->ddelta, (3 * (size_t)d * r + (size_t)r * lda + lda + 16) * sizeof(float),
+                              "dictionary deltas"));
+        float* Ap = (float*)c->ddelta.p;             // 64-byte aligned rows
+        float* inv = Ap + (size_t)r * lda;
+        float* Dt = inv + lda;
+        float* Wt = Dt + (size_t)d * r;              // W^T in, r x d
+        float* WtOut = Wt + (size_t)d * r;
+        ONMF_TRY(launch_transpose(d, r, Win, Wt, s));
+        hipLaunchKernelGGL(dict_pad_kernel, dim3(r), dim3(64), 0, s, r, lda, A, Ap, inv);
+        HIP_TRY(c, hipGetLastError());
+        const int rpt = (d + 1023) / 1024;
+        const int nt = rpt > 1 ? 1024 : (d + 63) / 64 * 64;
+#define PANEL_CASE(RPTV, PWV)                                                                          \
+    hipLaunchKernelGGL((dict_panel_kernel<RPTV, PWV>), dim3(1), dim3(nt), 0, s, d, r, lda, Qt, Ap, inv, B, \
+                       Wt, WtOut, Dt)
+        switch (rpt) {
+            case 1: PANEL_CASE(1, 16); break;
+            case 2: PANEL_CASE(2, 16); break;
+            case 3: PANEL_CASE(3, 8); break;
+            default: PANEL_CASE(4, 8); break;
+        }
+#undef PANEL_CASE
+        HIP_TRY(c, hipGetLastError());
+        return launch_transpose(r, d, WtOut, Wout, s);
+    }
+    if (c->dict_kernel == 2)
+        return onmf_fail(c, ONMF_ERR_ARG, "update_dict: the one-workgroup kernel covers d <= 4096 (d=%d)", d);
+    c->dict_coop_last = true;
     const int nwg = (d + 63) / 64;
     if (nwg > 256)
         return onmf_fail(c, ONMF_ERR_ARG, "update_dict: d=%d needs %d co-resident workgroups (max 256)", d, nwg);

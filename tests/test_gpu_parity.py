@@ -290,17 +290,41 @@ def test_step_against_oracle(eng, orc, d, r, b, kernel):
     assert relerr(host(W1), W_o) < TOL_W
 
 
-def test_update_dict_many_workgroups(eng, orc):
-    """d = 1500 -> 24 cooperating workgroups in the dictionary pass."""
-    rs = np.random.RandomState(77)
-    d, r = 1500, 48
+@pytest.mark.parametrize("kernel", [1, 2])
+@pytest.mark.parametrize("shape", [(1500, 48), (64, 16), (1024, 256), (2500, 40), (4096, 23), (33, 7)])
+def test_update_dict_both_kernels(eng, orc, kernel, shape):
+    """The dictionary pass with cooperating workgroups (1; d = 1500 -> 24 of them) and inside one
+    workgroup (2; one to four rows per thread, panels of 16 or 8 atoms), against the oracle."""
+    d, r = shape
+    rs = np.random.RandomState(77 + d)
     W = rs.rand(d, r)
     Hw = rs.rand(r, 400)
-    A = Hw @ Hw.T
-    B = Hw @ rs.rand(d, 400).T
-    W1 = host(eng.update_dict(eng.dev(W), eng.dev(A), eng.dev(B)))
+    A = Hw @ Hw.T / 400          # aggregates are running means of H H^T and H X^T
+    B = Hw @ rs.rand(d, 400).T / 400
+    eng.set_option(6, kernel)
+    try:
+        W1 = host(eng.update_dict(eng.dev(W), eng.dev(A), eng.dev(B)))
+    finally:
+        eng.set_option(6, 0)
     assert relerr(W1, orc.dictionary_pass(W, A, B)) < TOL_W
     assert np.linalg.norm(W1, axis=0).max() <= 1 + 1e-5
+
+
+def test_update_dict_small_aggregates_keep_norms_below_one(eng, orc):
+    """Aggregates scaled so that most atoms end inside the unit ball (no projection)."""
+    rs = np.random.RandomState(5)
+    d, r = 700, 33
+    W = rs.rand(d, r) * 0.02
+    Hw = rs.rand(r, 50)
+    A = Hw @ Hw.T
+    B = Hw @ (0.02 * rs.rand(d, 50)).T
+    for kernel in (1, 2):
+        eng.set_option(6, kernel)
+        try:
+            W1 = host(eng.update_dict(eng.dev(W), eng.dev(A), eng.dev(B)))
+        finally:
+            eng.set_option(6, 0)
+        assert relerr(W1, orc.dictionary_pass(W, A, B)) < TOL_W
 
 
 def test_torch_in_torch_out_and_device_rng(eng):
