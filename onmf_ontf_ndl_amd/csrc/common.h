@@ -120,6 +120,7 @@ struct ScreenLayout {           // offsets in floats into ctx->screen
     static constexpr int SUMS = YACC + SCREEN_REPL * 256;          // REPL x 2 doubles (8-byte aligned)
     static constexpr int FLAG = SUMS + SCREEN_REPL * 4;            // int
     static constexpr int UBPREV = FLAG + 1;        // float: upper bound of sigma_max(H before the sweep)
+    static constexpr int SKIP = FLAG + 2;          // int: the next sweep's probe power step is skipped
     static constexpr int AVEC = FLAG + 4;          // 16: last Ritz coefficient vector (warm start)
     static constexpr int REC = AVEC + 16;          // SCREEN_MAX_SWEEPS x 4 floats
     static constexpr int TOTAL = REC + 4 * SCREEN_MAX_SWEEPS;

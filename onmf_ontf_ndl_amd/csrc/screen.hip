@@ -66,6 +66,7 @@ __global__ __launch_bounds__(256) void screen_refresh_kernel(int r, int b, int s
     __shared__ float sd[4][16 * 17];
     __shared__ float sp[16 * 17];
     if (reinterpret_cast<const int*>(base)[ScreenLayout::FLAG] != 0) return;
+    if (reinterpret_cast<const int*>(base)[ScreenLayout::SKIP] != 0) return;   // probes good enough (uniform)
     const float* ublk = base + ScreenLayout::UBLK;
     float* zacc = base + ScreenLayout::ZACC + (blockIdx.x % SCREEN_ZREPL) * 4096;
     const int tid = threadIdx.x;
@@ -151,19 +152,24 @@ __global__ __launch_bounds__(256) void screen_decide_kernel(float* base, int r, 
     __shared__ float Z[256 * 17];
     __shared__ float M[16 * 16];      // Z^T Z
     __shared__ float avec[16], mvec[16], nrm[16], red[4];
-    __shared__ int entry_s;
+    __shared__ int entry_s, skip_s;
     int* flagp = reinterpret_cast<int*>(base) + ScreenLayout::FLAG;
+    int* skipp = reinterpret_cast<int*>(base) + ScreenLayout::SKIP;
     const int tid = threadIdx.x;
-    if (tid == 0) entry_s = *flagp;
+    if (tid == 0) {
+        entry_s = *flagp;
+        skip_s = *skipp;
+    }
     __syncthreads();
     if (entry_s != 0) return;                                 // loop already ended (uniform exit)
+    const bool refreshed = skip_s == 0;                       // the power step ran after this sweep
     float* vvec = base + ScreenLayout::V;
 
     // ---- gather the replicated accumulators (and clear them for the next sweep) ----
     float zrow[16];
 #pragma unroll
     for (int p = 0; p < 16; ++p) zrow[p] = 0.f;
-    for (int rep = 0; rep < SCREEN_ZREPL; ++rep) {
+    for (int rep = 0; rep < (refreshed ? SCREEN_ZREPL : 0); ++rep) {
         float4* zp = reinterpret_cast<float4*>(base + ScreenLayout::ZACC + rep * 4096 + tid * 16);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -229,6 +235,9 @@ __global__ __launch_bounds__(256) void screen_decide_kernel(float* base, int r, 
         rec[2] = (float)(verdict + 1);                        // 0 = sweep did not run
         rec[3] = (float)ubH;                                  // upper bound of sigma_max(H before the sweep)
         if (verdict != 0) *flagp = verdict;
+        // A lower bound well above the tolerance needs no better probes: the next sweep skips the
+        // power step (and this kernel the probe update) until the margin shrinks.
+        *skipp = (verdict == 0 && lower > 1.5 * (double)tol) ? 1 : 0;
     }
 
     // ---- Collatz-Wielandt bound of sigma_max(H_new) for the next sweep's test, next v ----
@@ -238,6 +247,7 @@ __global__ __launch_bounds__(256) void screen_decide_kernel(float* base, int r, 
     const float ymax = block_max(yk, red);                    // (its barriers also publish Z)
     if (tid == 0) base[ScreenLayout::UBPREV] = (cw > 0.f) ? sqrtf(cw) * (1.0f + 2e-4f) : -1.0f;
     if (tid < r) vvec[tid] = (ymax > 0.f) ? (yk / ymax + 1e-3f) : 1.0f;
+    if (!refreshed) return;                                   // uniform: keep the probes as they are
 
     // ---- refresh the probes ----
     // M = Z^T Z; a = its top eigenvector (a few power steps); t = Z a is the dominant direction of
