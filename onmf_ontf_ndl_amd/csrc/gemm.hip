@@ -4,10 +4,15 @@
 //   Gm = W^T W, Cm = W^T X      (contraction index is the slow index of both operands)
 //   H H^T, H X^T, X X^T         (contraction index is the fast index of both operands)
 //   Qt = A^T W^T                (mixed)
-// Operand tiles are staged in LDS in "k-major" form [BK][128]; an operand whose memory layout
-// is [x][k] is transposed on the way into LDS (row pitch 129 keeps those scattered stores and
-// the later row reads conflict-free).  Each of the 4 waves owns a 64x64 block of the 128x128
-// output tile as 2x2 v_mfma_f32_32x32x2_f32 accumulators (exact fp32, k-ordered fma chain).
+// Operand tiles are staged in LDS as [x][k] (x = row of the output tile for A, column for B; the
+// BK = 32 contraction indices of a row are contiguous), in 16-byte chunks of four k that are
+// XOR-swizzled per row so that all three access patterns are bank-conflict-free: 16-byte stores
+// when memory is [x][k], transposing 4-byte stores when memory is [k][x], and the 16-byte operand
+// reads.  One such read hands a lane four k values of its row, i.e. its operand for four MFMAs:
+// lanes 0-31 take chunk 2q, lanes 32-63 chunk 2q+1, so MFMA j of round q contracts k = 8q + j and
+// 8q + 4 + j (any fixed pairing is valid as long as A and B use the same one).
+// Each of the 4 waves owns a 64x64 block of the 128x128 output tile as 2x2
+// v_mfma_f32_32x32x2_f32 accumulators (exact fp32).
 // Long contractions (K = batch) are split over blockIdx.z into slabs that a second kernel sums
 // in a fixed order, so results are bitwise reproducible.
 #include "common.h"
@@ -18,8 +23,13 @@ constexpr int BM = 128;
 constexpr int BN = 128;
 constexpr int BK = 32;
 constexpr int NTHREADS = 256;
-constexpr int PITCH_KMAJ = 128;   // memory already k-major: float4 row copies
-constexpr int PITCH_XMAJ = 129;   // transposing store: (k*129 + x) spreads over all 32 banks
+constexpr int TILE_ELEMS = 128 * BK;      // one operand tile in LDS (16 KB)
+
+// dword offset of element (x, k) of an LDS operand tile
+__device__ __forceinline__ int lds_off(int x, int k) {
+    const int sw = (x & 7) ^ (2 * ((x >> 3) & 1));
+    return x * BK + 4 * ((k >> 2) ^ sw) + (k & 3);
+}
 
 struct GemmParams {
     const float* A;
@@ -37,6 +47,8 @@ struct GemmParams {
 };
 
 // Global -> registers for one BK x 128 operand tile (4 float4 per thread).
+// KMAJ (memory [k][x]): thread t takes k = (t & 7) + 8p, x = 4 (t >> 3) .. +3 - a wave reads 8 rows
+// of 128 contiguous bytes.  Otherwise (memory [x][k]): x = (t >> 3) + 32p, k = 4 (t & 7) .. +3.
 template <bool KMAJ>
 __device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, int xdim, int x0,
                                           int k0, int kend, int vec_ok, float4 (&rg)[4]) {
@@ -45,8 +57,8 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, i
     for (int p = 0; p < 4; ++p) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (KMAJ) {
-            const int k = k0 + (t >> 5) + 8 * p;
-            const int x = x0 + (t & 31) * 4;
+            const int k = k0 + (t & 7) + 8 * p;
+            const int x = x0 + (t >> 3) * 4;
             if (k < kend) {
                 const float* src = P + (size_t)k * ld + x;
                 if (vec_ok && x + 3 < xdim) {
@@ -77,39 +89,80 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, i
     }
 }
 
-// Registers -> LDS, always producing the k-major image S[k][x].
+// Registers -> LDS tile S[x][k] (swizzled).
 template <bool KMAJ>
 __device__ __forceinline__ void store_tile(float* __restrict__ S, const float4 (&rg)[4]) {
     const int t = threadIdx.x;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         if (KMAJ) {
-            const int k = (t >> 5) + 8 * p;
-            const int x = (t & 31) * 4;
-            *reinterpret_cast<float4*>(S + k * PITCH_KMAJ + x) = rg[p];
+            const int k = (t & 7) + 8 * p;
+            const int x = (t >> 3) * 4;
+            S[lds_off(x + 0, k)] = rg[p].x;
+            S[lds_off(x + 1, k)] = rg[p].y;
+            S[lds_off(x + 2, k)] = rg[p].z;
+            S[lds_off(x + 3, k)] = rg[p].w;
         } else {
             const int x = (t >> 3) + 32 * p;
             const int k = (t & 7) * 4;
-            S[(k + 0) * PITCH_XMAJ + x] = rg[p].x;
-            S[(k + 1) * PITCH_XMAJ + x] = rg[p].y;
-            S[(k + 2) * PITCH_XMAJ + x] = rg[p].z;
-            S[(k + 3) * PITCH_XMAJ + x] = rg[p].w;
+            *reinterpret_cast<float4*>(S + lds_off(x, k)) = rg[p];
         }
     }
 }
 
+// Tile source.  Interior tiles of aligned operands come through a buffer descriptor: the per-thread
+// byte offsets are computed once, the tile origin is a scalar offset, so a tile costs no vector
+// arithmetic at all (vector ALU cycles are not hidden behind fp32 MFMAs on this chip).  Edge tiles
+// and unaligned operands take the checked path.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <bool KMAJ>
+struct TileSource {
+    const float* P;
+    int ld, xdim, x0, kbeg, kend, vec_ok;
+    bool fast;
+    __amdgpu_buffer_rsrc_t rs;
+    int voff[4];
+    unsigned soff0, sstep;
+
+    __device__ __forceinline__ void init(const float* P_, int ld_, int xdim_, int kdim, int x0_, int kbeg_,
+                                         int kend_, int vec_ok_) {
+        P = P_; ld = ld_; xdim = xdim_; x0 = x0_; kbeg = kbeg_; kend = kend_; vec_ok = vec_ok_;
+        const int t = threadIdx.x;
+        const size_t rows = KMAJ ? (size_t)kdim : (size_t)xdim;
+        const size_t bytes = rows * (size_t)ld * sizeof(float);
+        fast = vec_ok && (x0 + 128 <= xdim) && bytes < 0xfffff000ull;
+        rs = __builtin_amdgcn_make_buffer_rsrc((void*)P, 0, (unsigned)(fast ? bytes : 0), 0x00020000);
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            voff[p] = KMAJ ? (((t & 7) + 8 * p) * ld + (t >> 3) * 4) * 4 : (((t >> 3) + 32 * p) * ld + (t & 7) * 4) * 4;
+        soff0 = KMAJ ? (unsigned)(((size_t)kbeg * ld + x0) * 4) : (unsigned)(((size_t)x0 * ld + kbeg) * 4);
+        sstep = KMAJ ? (unsigned)((size_t)BK * ld * 4) : (unsigned)(BK * 4);
+    }
+    __device__ __forceinline__ void load(int tile, float4 (&rg)[4]) const {
+        const int k0 = kbeg + tile * BK;
+        if (fast && k0 + BK <= kend) {                       // uniform
+            const unsigned so = soff0 + (unsigned)tile * sstep;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff[p], so, 0);
+                rg[p] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]),
+                                    __uint_as_float(v[3]));
+            }
+        } else {
+            load_tile<KMAJ>(P, ld, xdim, x0, k0, kend, vec_ok, rg);
+        }
+    }
+};
+
 template <bool A_KM, bool B_KN>
 __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int PA = A_KM ? PITCH_KMAJ : PITCH_XMAJ;
-    constexpr int PB = B_KN ? PITCH_KMAJ : PITCH_XMAJ;
-    constexpr int A_ELEMS = BK * PA;
-    constexpr int B_ELEMS = BK * PB;
-    // layout: [A buf0][A buf1][B buf0][B buf1]; every part starts 16-byte aligned
-    constexpr int A_STRIDE = (A_ELEMS + 3) & ~3;
-    constexpr int B_STRIDE = (B_ELEMS + 3) & ~3;
+    // layout: [A buf0][A buf1][B buf0][B buf1]
+    constexpr int A_STRIDE = TILE_ELEMS;
+    constexpr int B_STRIDE = TILE_ELEMS;
     float* As = lds;
-    float* Bs = lds + 2 * A_STRIDE;
+    float* Bs = lds + 2 * TILE_ELEMS;
 
     const int tile = blockIdx.x;
     const int m0 = (tile / p.tiles_n) * BM;
@@ -133,42 +186,64 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    float4 ra[4], rb[4];
+    // Software pipeline over the k-tiles, two tiles deep: tile t+2 travels from memory to
+    // registers while tile t+1 (in registers since the previous round) is written to the free LDS
+    // buffer in the middle of tile t's MFMAs.  The barrier at the end of a round then waits for
+    // LDS stores only, never for memory.  Rounds come in pairs so the two register sets swap
+    // roles without copies.
+    float4 ra[4], rb[4], ra2[4], rb2[4];
     const int ntiles = (kend - kbeg + BK - 1) / BK;
+    TileSource<A_KM> srcA;
+    TileSource<B_KN> srcB;
+    srcA.init(p.A, p.lda, p.M, p.K, m0, kbeg, kend, p.vecA);
+    srcB.init(p.B, p.ldb, p.N, p.K, n0, kbeg, kend, p.vecB);
     if (ntiles > 0) {
-        load_tile<A_KM>(p.A, p.lda, p.M, m0, kbeg, kend, p.vecA, ra);
-        load_tile<B_KN>(p.B, p.ldb, p.N, n0, kbeg, kend, p.vecB, rb);
+        srcA.load(0, ra);
+        srcB.load(0, rb);
         store_tile<A_KM>(As, ra);
         store_tile<B_KN>(Bs, rb);
+        if (ntiles > 1) {
+            srcA.load(1, ra);
+            srcB.load(1, rb);
+        }
     }
     __syncthreads();
 
-    for (int t = 0; t < ntiles; ++t) {
+    // one round: MFMAs of tile t; (xa, xb) hold tile t+1, (ya, yb) receive tile t+2
+    auto round = [&](int t, float4 (&xa)[4], float4 (&xb)[4], float4 (&ya)[4], float4 (&yb)[4]) {
         const int cur = t & 1;
-        const bool more = (t + 1 < ntiles);
-        if (more) {
-            load_tile<A_KM>(p.A, p.lda, p.M, m0, kbeg + (t + 1) * BK, kend, p.vecA, ra);
-            load_tile<B_KN>(p.B, p.ldb, p.N, n0, kbeg + (t + 1) * BK, kend, p.vecB, rb);
+        if (t + 2 < ntiles) {
+            srcA.load(t + 2, ya);
+            srcB.load(t + 2, yb);
         }
         const float* Ac = As + cur * A_STRIDE;
         const float* Bc = Bs + cur * B_STRIDE;
 #pragma unroll
-        for (int s = 0; s < BK / 2; ++s) {
-            const int k = 2 * s + lhi;
-            const float a0 = Ac[k * PA + wm + l31];
-            const float a1 = Ac[k * PA + wm + 32 + l31];
-            const float b0 = Bc[k * PB + wn + l31];
-            const float b1 = Bc[k * PB + wn + 32 + l31];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-        }
-        if (more) {
-            store_tile<A_KM>(As + (cur ^ 1) * A_STRIDE, ra);
-            store_tile<B_KN>(Bs + (cur ^ 1) * B_STRIDE, rb);
+        for (int q = 0; q < BK / 8; ++q) {
+            if (q == BK / 16 && t + 1 < ntiles) {
+                store_tile<A_KM>(As + (cur ^ 1) * A_STRIDE, xa);
+                store_tile<B_KN>(Bs + (cur ^ 1) * B_STRIDE, xb);
+            }
+            const int k = 8 * q + 4 * lhi;
+            const float4 a0 = *reinterpret_cast<const float4*>(Ac + lds_off(wm + l31, k));
+            const float4 a1 = *reinterpret_cast<const float4*>(Ac + lds_off(wm + 32 + l31, k));
+            const float4 b0 = *reinterpret_cast<const float4*>(Bc + lds_off(wn + l31, k));
+            const float4 b1 = *reinterpret_cast<const float4*>(Bc + lds_off(wn + 32 + l31, k));
+            const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
+            const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[j], bv0[j], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[j], bv1[j], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[j], bv0[j], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[j], bv1[j], acc[1][1], 0, 0, 0);
+            }
         }
         __syncthreads();
+    };
+    for (int t = 0; t < ntiles; t += 2) {
+        round(t, ra, rb, ra2, rb2);
+        if (t + 1 < ntiles) round(t + 1, ra2, rb2, ra, rb);
     }
 
     // accumulator element e of lane l: row (e&3) + 8*(e>>2) + 4*(l>>5), column l&31
@@ -214,10 +289,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 template <bool A_KM, bool B_KN>
 int run(onmf_ctx* c, const GemmParams& p, dim3 grid, hipStream_t s) {
-    constexpr int PA = A_KM ? PITCH_KMAJ : PITCH_XMAJ;
-    constexpr int PB = B_KN ? PITCH_KMAJ : PITCH_XMAJ;
-    constexpr size_t bytes =
-        sizeof(float) * 2 * ((((size_t)BK * PA + 3) & ~(size_t)3) + (((size_t)BK * PB + 3) & ~(size_t)3));
+    constexpr size_t bytes = sizeof(float) * 4 * TILE_ELEMS;
     static bool attr_done = false;
     if (!attr_done) {
         HIP_TRY(c, hipFuncSetAttribute((const void*)gemm_f32_kernel<A_KM, B_KN>,
