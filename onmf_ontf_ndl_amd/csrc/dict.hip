@@ -102,17 +102,22 @@ struct alignas(64) Row16 {
     float v[16];
 };
 
-// sum over the wave, returned wave-uniform (DPP row sums, then the four row totals)
-__device__ __forceinline__ float wave_sum_uniform(float x) {
+// sum of a row of 16 lanes, left in lane 15 of the row (row_shr 1, 2, 4, 8)
+__device__ __forceinline__ float row_total(float x) {
     x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x111, 0xf, 0xf, true));
     x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x112, 0xf, 0xf, true));
     x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x114, 0xf, 0xf, true));
     x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x118, 0xf, 0xf, true));
-    const int xi = __builtin_bit_cast(int, x);
-    return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 15)) +
-            __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 31))) +
-           (__builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 47)) +
-            __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 63)));
+    return x;
+}
+
+// sum over the wave, returned wave-uniform: row totals, then row_bcast15 into rows 1 and 3,
+// row_bcast31 into rows 2 and 3; lane 63 holds the total
+__device__ __forceinline__ float wave_sum_uniform(float x) {
+    x = row_total(x);
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x142, 0xa, 0xf, true));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x143, 0xc, 0xf, true));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
 }
 
 // Ap[k][0..lda) = A[k][0..r) followed by zeros; inv[k] = 1 / (A[k][k] + 1)
@@ -137,27 +142,36 @@ __global__ __launch_bounds__(1024) void dict_panel_kernel(int d, int r, int lda,
     __shared__ __attribute__((aligned(16))) float part[2][16];   // one slot per wave; unused slots stay 0
     const int tid = threadIdx.x;
     const int wave = tid >> 6;
+    const bool lane0 = (tid & 63) == 0;
     if (tid < 32) part[tid >> 4][tid & 15] = 0.f;
     __syncthreads();
-    int row[RPT];          // clamped: rows past the end compute on a copy of row d-1 and store nothing
-    bool valid[RPT];
+    // All [atom][row] arrays go through buffer descriptors: byte address = per-thread row offset +
+    // wave-uniform atom offset, no per-access vector arithmetic; rows past d and atoms past r read
+    // 0 and drop their stores (range check), so they need no masks: their u is max(0 - 0, 0) = 0.
+    const unsigned nbytes = (unsigned)r * (unsigned)d * 4u;
+    const auto rs_q = __builtin_amdgcn_make_buffer_rsrc((void*)Qt0, 0, nbytes, 0x00020000);
+    const auto rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, nbytes, 0x00020000);
+    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)Wt, 0, nbytes, 0x00020000);
+    const auto rs_o = __builtin_amdgcn_make_buffer_rsrc((void*)WtOut, 0, nbytes, 0x00020000);
+    const auto rs_d = __builtin_amdgcn_make_buffer_rsrc((void*)Dt, 0, nbytes, 0x00020000);
+    int voff[RPT];
 #pragma unroll
     for (int p = 0; p < RPT; ++p) {
         const int i = tid + p * (int)blockDim.x;
-        valid[p] = i < d;
-        row[p] = min(i, d - 1);
+        voff[p] = i < d ? i * 4 : (int)0x80000000;
     }
+    const int rowbytes = d * 4;
     for (int j0 = 0; j0 < r; j0 += PW) {
         float q[RPT][PW], w[RPT][PW];
-        // this panel's entries of Q0 - B and of W (atoms past the end: copies of atom r-1, unused)
+        // this panel's entries of Q0 - B and of W
 #pragma unroll
         for (int p = 0; p < RPT; ++p) {
 #pragma unroll
             for (int n = 0; n < PW; ++n) {
-                const int j = min(j0 + n, r - 1);
-                const size_t at = (size_t)j * d + row[p];
-                q[p][n] = Qt0[at] - B[at];
-                w[p][n] = Wt[at];
+                const int so = (j0 + n) * rowbytes;
+                q[p][n] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_q, voff[p], so, 0)) -
+                          __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_b, voff[p], so, 0));
+                w[p][n] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_w, voff[p], so, 0));
             }
         }
         // left-looking update from the atoms before the panel; the deltas of the next four atoms
@@ -167,7 +181,8 @@ __global__ __launch_bounds__(1024) void dict_panel_kernel(int d, int r, int lda,
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-                for (int p = 0; p < RPT; ++p) dn[p][kk] = Dt[(size_t)kk * d + row[p]];
+                for (int p = 0; p < RPT; ++p)
+                    dn[p][kk] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_d, voff[p], kk * rowbytes, 0));
         }
         for (int k = 0; k < j0; k += 4) {
             float dl[RPT][4];
@@ -177,7 +192,8 @@ __global__ __launch_bounds__(1024) void dict_panel_kernel(int d, int r, int lda,
 #pragma unroll
                 for (int p = 0; p < RPT; ++p) {
                     dl[p][kk] = dn[p][kk];
-                    dn[p][kk] = Dt[(size_t)(kn + kk) * d + row[p]];
+                    dn[p][kk] = __uint_as_float(
+                        __builtin_amdgcn_raw_buffer_load_b32(rs_d, voff[p], (kn + kk) * rowbytes, 0));
                 }
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
@@ -197,43 +213,42 @@ __global__ __launch_bounds__(1024) void dict_panel_kernel(int d, int r, int lda,
             }
         }
         // The panel's atoms in order (padded atoms j >= r run on zeros of Ap: harmless, not stored).
-        // The barrier below orders LDS traffic only: waiting for the global stores of the deltas as
-        // well (what __syncthreads would do) costs a memory round trip per atom.  The row of A for
-        // the next atom is fetched right after the barrier, a whole atom ahead of its use.
+        // Every instruction here is paid by all 16 waves on 4 SIMDs, once per atom, in a chain that
+        // nothing overlaps: the norm takes 7 cross-lane steps per wave, one LDS slot per wave, a
+        // barrier that orders LDS traffic only (waiting for the global stores as well, as
+        // __syncthreads would, costs a memory round trip per atom), one LDS read per lane and 5 more
+        // cross-lane steps; 1 / max(1, norm) is one v_rsq_f32.  The row of A for the next atom is
+        // fetched right after the barrier, a whole atom ahead of its use.
         const Row16 inv16 = *reinterpret_cast<const Row16*>(inv_diag + (j0 & ~15));
         Row16 acur = *reinterpret_cast<const Row16*>(Ap + (size_t)min(j0, r - 1) * lda + (j0 & ~15));
 #pragma unroll
         for (int n = 0; n < PW; ++n) {
             const int j = j0 + n;
-            const float inv = inv16.v[(j0 & 15) + n];
+            const float ninv = -inv16.v[(j0 & 15) + n];
             float u[RPT];
             float ss = 0.f;
 #pragma unroll
             for (int p = 0; p < RPT; ++p) {
-                u[p] = fmaxf(w[p][n] - q[p][n] * inv, 0.f);
-                ss = valid[p] ? fmaf(u[p], u[p], ss) : ss;
+                u[p] = fmaxf(fmaf(q[p][n], ninv, w[p][n]), 0.f);
+                ss = fmaf(u[p], u[p], ss);
             }
             const float ws = wave_sum_uniform(ss);
-            if ((tid & 63) == 0) part[n & 1][wave] = ws;
+            if (lane0) part[n & 1][wave] = ws;
             __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): the LDS write has landed
             __builtin_amdgcn_s_barrier();
             Row16 anext = acur;
             if (n + 1 < PW)
                 anext = *reinterpret_cast<const Row16*>(Ap + (size_t)min(j + 1, r - 1) * lda + (j0 & ~15));
-            // all 16 slots in one LDS round, summed in a fixed order by every thread
-            const float4* pp = reinterpret_cast<const float4*>(part[n & 1]);
-            const float4 s0 = pp[0], s1 = pp[1], s2 = pp[2], s3 = pp[3];
-            const float total = (((s0.x + s0.y) + (s0.z + s0.w)) + ((s1.x + s1.y) + (s1.z + s1.w))) +
-                                (((s2.x + s2.y) + (s2.z + s2.w)) + ((s3.x + s3.y) + (s3.z + s3.w)));
-            const float scale = 1.0f / fmaxf(1.0f, sqrtf(total));
+            // the 16 slots, one per lane of a row, summed by the same tree in every wave
+            const float total = __builtin_bit_cast(
+                float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, row_total(part[n & 1][tid & 15])), 15));
+            const float scale = total > 1.0f ? __builtin_amdgcn_rsqf(total) : 1.0f;
 #pragma unroll
             for (int p = 0; p < RPT; ++p) {
                 const float wn = u[p] * scale;
                 const float dv = wn - w[p][n];
-                if (valid[p] && j < r) {
-                    WtOut[(size_t)j * d + row[p]] = wn;
-                    Dt[(size_t)j * d + row[p]] = dv;
-                }
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(wn), rs_o, voff[p], j * rowbytes, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dv), rs_d, voff[p], j * rowbytes, 0);
 #pragma unroll
                 for (int m = n + 1; m < PW; ++m) q[p][m] = fmaf(acur.v[(j0 & 15) + m], dv, q[p][m]);
             }
