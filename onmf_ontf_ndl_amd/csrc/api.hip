@@ -287,7 +287,6 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
     ONMF_TRY(onmf_reserve(c, c->gram, (size_t)r * r * sizeof(float), "Gm"));
     ONMF_TRY(onmf_reserve(c, c->cm, rb * sizeof(float), "Cm"));
     ONMF_TRY(onmf_reserve(c, c->hbuf[0], rb * sizeof(float), "code buffer"));
-    ONMF_TRY(onmf_reserve(c, c->hbuf[1], rb * sizeof(float), "code buffer"));
     const int max_groups = (b + 15) / 16 + 64;
     ONMF_TRY(onmf_reserve(c, c->stats, (size_t)max_groups * 2 * sizeof(double), "sweep statistics"));
     ONMF_TRY(onmf_reserve_pinned(c, std::max((size_t)max_groups * 2 * sizeof(double),
@@ -297,9 +296,14 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
     // Gm = W^T W,  Cm = W^T X   (src/onmf.py:242-243)
     ONMF_TRY(launch_gemm(c, true, true, r, r, d, W, r, W, r, 1.f, 0.f, nullptr, Gm, r, s));
     ONMF_TRY(launch_gemm(c, true, true, r, b, d, W, r, X, ldx, 1.f, 0.f, nullptr, Cm, b, s));
-    float* buf[2] = {(float*)c->hbuf[0].p, (float*)c->hbuf[1].p};
+    // Sweep i reads buf[i & 1] and writes buf[(i + 1) & 1].  The caller's H is one of the two
+    // buffers, placed so that a solve that runs all sub_iter sweeps ends in it (no final copy).
+    float* buf[2];
+    buf[sub_iter & 1] = H;
+    buf[(sub_iter + 1) & 1] = (float*)c->hbuf[0].p;
     if (H0) {
-        HIP_TRY(c, hipMemcpyAsync(buf[0], H0, rb * sizeof(float), hipMemcpyDeviceToDevice, s));
+        if (H0 != buf[0])
+            HIP_TRY(c, hipMemcpyAsync(buf[0], H0, rb * sizeof(float), hipMemcpyDeviceToDevice, s));
     } else {
         ONMF_TRY(launch_fill_uniform(buf[0], rb, seed, s));
     }
@@ -307,7 +311,7 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
     const double rank_cap = (double)std::min(r, b);
     const int exact_cd = (coder_mode == ONMF_CODER_EXACT_CD);
     const double nan = std::numeric_limits<double>::quiet_NaN();
-    int done = 0;           // sweep i reads buf[i & 1] and writes buf[(i + 1) & 1]
+    int done = 0;
 
     const bool screened = !exact_cd && tol > 0.0 && !c->exact_stop && c->screen_stop &&
                           c->sweep_kernel != 1 && sweep_tile_covers(r, b) &&
@@ -420,7 +424,8 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
             ++done;
         }
     }
-    HIP_TRY(c, hipMemcpyAsync(H, buf[done & 1], rb * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (buf[done & 1] != H)
+        HIP_TRY(c, hipMemcpyAsync(H, buf[done & 1], rb * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (sweeps_done) *sweeps_done = done;
     if (dist_trace)
         for (int i = done; i < sub_iter; ++i) dist_trace[i] = std::numeric_limits<float>::quiet_NaN();
