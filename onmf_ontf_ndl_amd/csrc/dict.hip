@@ -98,6 +98,21 @@ __global__ __launch_bounds__(64) void dict_pass_kernel(int d, int r, int nwg,
 // once.  No state is shared between threads except the norm partials.  W is read and written
 // transposed ([atom][row], contiguous along a wave); the launcher transposes on the way in and out.
 // ---------------------------------------------------------------------------------------------
+// 4x4 transpose between a register index and the lane row (16-lane group) of a wave: afterwards
+// register j of lane row g holds what register g of lane row j held (v_permlane32_swap exchanges
+// rows 2,3 of its first operand with rows 0,1 of the second; v_permlane16_swap the odd rows of the
+// first with the even rows of the second).
+__device__ __forceinline__ void xpose4(float& r0, float& r1, float& r2, float& r3) {
+    auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(r0), __float_as_uint(r2), false, false);
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(r1), __float_as_uint(r3), false, false);
+    auto c = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
+    auto d = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
+    r0 = __uint_as_float(c[0]);
+    r1 = __uint_as_float(c[1]);
+    r2 = __uint_as_float(d[0]);
+    r3 = __uint_as_float(d[1]);
+}
+
 struct alignas(64) Row16 {
     float v[16];
 };
@@ -174,41 +189,91 @@ __global__ __launch_bounds__(1024) void dict_panel_kernel(int d, int r, int lda,
                 w[p][n] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_w, voff[p], so, 0));
             }
         }
-        // left-looking update from the atoms before the panel; the deltas of the next four atoms
-        // are fetched while the current four are applied
-        float dn[RPT][4];
-        if (j0 > 0) {
+        if constexpr (RPT == 1 && PW == 16) {
+            // Left-looking update from the atoms before the panel, on the matrix cores (twice the
+            // vector rate for fp32).  Per wave, for its 4 tiles of 16 rows:
+            //     D[atom n][row] += sum_k Ap[k][j0 + n] * Dt[k][row]        (v_mfma_f32_16x16x4_f32)
+            // A operand: lane (g, c) = Ap[k0 + g][j0 + c]; B operand: Dt[k0 + g][tile row c].
+            // D leaves atoms 4g..4g+3 of row c in lane (g, c); a 4x4 transpose between the tile
+            // index and the lane row then hands lane 16g + c all 16 atoms of ITS row (tile g, row c).
+            const int lane = tid & 63, c16 = lane & 15, g4 = lane >> 4;
+            const auto rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)Ap, 0, (unsigned)r * (unsigned)lda * 4u, 0x00020000);
+            const int voffA = (g4 * lda + c16) * 4;
+            int voffB[4];
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
+            for (int mt = 0; mt < 4; ++mt) {
+                const int rowb = wave * 64 + 16 * mt + c16;
+                voffB[mt] = rowb < d ? (rowb + g4 * d) * 4 : (int)0x80000000;
+            }
+            f32x4 D[4];
 #pragma unroll
-                for (int p = 0; p < RPT; ++p)
-                    dn[p][kk] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_d, voff[p], kk * rowbytes, 0));
-        }
-        for (int k = 0; k < j0; k += 4) {
-            float dl[RPT][4];
-            const int kn = min(k + 4, j0 - 4);           // last round: fetches its own group again
+            for (int mt = 0; mt < 4; ++mt) D[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            float an = 0.f, bn[4] = {0.f, 0.f, 0.f, 0.f};
+            if (j0 > 0) {
+                an = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_a, voffA, j0 * 4, 0));
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
+                for (int mt = 0; mt < 4; ++mt)
+                    bn[mt] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_d, voffB[mt], 0, 0));
+            }
+            for (int k0 = 0; k0 < j0; k0 += 4) {
+                const float a = an;
+                float bv[4];
 #pragma unroll
-                for (int p = 0; p < RPT; ++p) {
-                    dl[p][kk] = dn[p][kk];
-                    dn[p][kk] = __uint_as_float(
-                        __builtin_amdgcn_raw_buffer_load_b32(rs_d, voff[p], (kn + kk) * rowbytes, 0));
-                }
+                for (int mt = 0; mt < 4; ++mt) bv[mt] = bn[mt];
+                const int kn = min(k0 + 4, j0 - 4);          // last round: fetches its own group again
+                an = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_a, voffA, (kn * lda + j0) * 4, 0));
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                if (PW == 16) {
-                    const Row16 a = *reinterpret_cast<const Row16*>(Ap + (size_t)(k + kk) * lda + j0);
+                for (int mt = 0; mt < 4; ++mt)
+                    bn[mt] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_d, voffB[mt], kn * rowbytes, 0));
 #pragma unroll
-                    for (int n = 0; n < PW; ++n)
+                for (int mt = 0; mt < 4; ++mt) D[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[mt], D[mt], 0, 0, 0);
+            }
 #pragma unroll
-                        for (int p = 0; p < RPT; ++p) q[p][n] = fmaf(dl[p][kk], a.v[n], q[p][n]);
-                } else {
-                    const float* __restrict__ a = Ap + (size_t)(k + kk) * lda + j0;
-#pragma unroll
-                    for (int n = 0; n < PW; ++n)
-#pragma unroll
-                        for (int p = 0; p < RPT; ++p) q[p][n] = fmaf(dl[p][kk], a[n], q[p][n]);
+            for (int t = 0; t < 4; ++t) {
+                float x0 = D[0][t], x1 = D[1][t], x2 = D[2][t], x3 = D[3][t];
+                xpose4(x0, x1, x2, x3);
+                q[0][t] += x0;
+                q[0][4 + t] += x1;
+                q[0][8 + t] += x2;
+                q[0][12 + t] += x3;
+            }
+        } else {
+            // left-looking update from the atoms before the panel; the deltas of the next four atoms
+            // are fetched while the current four are applied
+            float dn[RPT][4];
+            if (j0 > 0) {
+    #pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+    #pragma unroll
+                    for (int p = 0; p < RPT; ++p)
+                        dn[p][kk] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_d, voff[p], kk * rowbytes, 0));
+            }
+            for (int k = 0; k < j0; k += 4) {
+                float dl[RPT][4];
+                const int kn = min(k + 4, j0 - 4);           // last round: fetches its own group again
+    #pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+    #pragma unroll
+                    for (int p = 0; p < RPT; ++p) {
+                        dl[p][kk] = dn[p][kk];
+                        dn[p][kk] = __uint_as_float(
+                            __builtin_amdgcn_raw_buffer_load_b32(rs_d, voff[p], (kn + kk) * rowbytes, 0));
+                    }
+    #pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    if (PW == 16) {
+                        const Row16 a = *reinterpret_cast<const Row16*>(Ap + (size_t)(k + kk) * lda + j0);
+    #pragma unroll
+                        for (int n = 0; n < PW; ++n)
+    #pragma unroll
+                            for (int p = 0; p < RPT; ++p) q[p][n] = fmaf(dl[p][kk], a.v[n], q[p][n]);
+                    } else {
+                        const float* __restrict__ a = Ap + (size_t)(k + kk) * lda + j0;
+    #pragma unroll
+                        for (int n = 0; n < PW; ++n)
+    #pragma unroll
+                            for (int p = 0; p < RPT; ++p) q[p][n] = fmaf(dl[p][kk], a[n], q[p][n]);
+                    }
                 }
             }
         }
