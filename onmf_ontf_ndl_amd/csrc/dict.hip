@@ -11,7 +11,7 @@
 // 8-byte {tag, value} word with an agent-scope store, and every workgroup sums all words in the
 // same fixed order, so all of them scale by the bitwise-identical norm.
 //
-// That kernel pays one cross-workgroup exchange per atom (microseconds each).  For d <= 4096 a
+// That kernel pays one cross-workgroup exchange per atom (microseconds each).  For d <= 1024 a
 // second kernel keeps the whole pass inside ONE workgroup (dict_panel_kernel below), where the
 // norm costs an LDS round and a barrier; it occupies a single CU and is several times faster.
 #include "common.h"
@@ -88,15 +88,15 @@ __global__ __launch_bounds__(64) void dict_pass_kernel(int d, int r, int nwg,
 }
 
 // ---------------------------------------------------------------------------------------------
-// One-workgroup pass.  Thread t owns rows t, t + 1024, ... (RPT of them).  Atoms are taken in
-// panels of PW.  For a panel starting at atom j0 the thread first brings its PW entries of
-// Q - B up to date from the deltas of all earlier atoms (left-looking: q[n] += delta_k * A[k][j0+n],
-// k < j0; its own deltas read back from `Dt`, stored [atom][row] so that a wave's access is one
-// contiguous line; the entries of A wave-uniform, fetched as 64-byte scalar loads from a copy of A
-// whose rows are padded with zeros to a multiple of 16), then runs the PW atoms in order: the norm
-// is a wave sum, one LDS slot per wave and a barrier; later atoms of the panel take the delta at
-// once.  No state is shared between threads except the norm partials.  W is read and written
-// transposed ([atom][row], contiguous along a wave); the launcher transposes on the way in and out.
+// One-workgroup pass (d <= 1024).  256 threads; thread t owns rows t, t + 256, ... (RPT of them).
+// Atoms are taken in panels of 16.  For a panel starting at atom j0 the workgroup first brings its
+// entries of Q - B up to date from the deltas of all earlier atoms (left-looking:
+// q[row][n] += sum_{k < j0} delta[k][row] * A[k][j0+n], an MFMA product; the deltas are read back
+// from `Dt`, stored [atom][row]), then runs the 16 atoms in order: the norm is a wave sum, one LDS
+// slot per wave and a barrier; later atoms of the panel take the delta at once, with the entries
+// of A wave-uniform (64-byte scalar loads from a copy of A whose rows are padded with zeros to a
+// multiple of 16).  W is read and written transposed ([atom][row], contiguous along a wave); the
+// launcher transposes on the way in and out.
 // ---------------------------------------------------------------------------------------------
 // 4x4 transpose between a register index and the lane row (16-lane group) of a wave: afterwards
 // register j of lane row g holds what register g of lane row j held (v_permlane32_swap exchanges
@@ -130,34 +130,36 @@ __device__ __forceinline__ float row_total(float x) {
 // row_bcast31 into rows 2 and 3; lane 63 holds the total
 __device__ __forceinline__ float wave_sum_uniform(float x) {
     x = row_total(x);
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x142, 0xa, 0xf, true));
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x143, 0xc, 0xf, true));
+    // rows outside row_mask keep x (the instruction leaves their destination alone)
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa\n\t"
+                 "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc\n\ts_nop 0"
+                 : "+v"(x));
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
 }
 
-// Ap[k][0..lda) = A[k][0..r) followed by zeros; inv[k] = 1 / (A[k][k] + 1)
-__global__ void dict_pad_kernel(int r, int lda, const float* __restrict__ A, float* __restrict__ Ap,
-                                float* __restrict__ inv) {
+// Ap[k][0..lda) = A[k][0..r) followed by zeros, except the diagonal, which the pass never reads as
+// an entry of A: Ap[k][k] = -1 / (A[k][k] + 1), the (negated) step of atom k
+__global__ void dict_pad_kernel(int r, int lda, const float* __restrict__ A, float* __restrict__ Ap) {
     const int k = blockIdx.x;
-    for (int j = threadIdx.x; j < lda; j += blockDim.x) Ap[(size_t)k * lda + j] = j < r ? A[(size_t)k * r + j] : 0.f;
-    if (threadIdx.x == 0) inv[k] = 1.0f / (A[(size_t)k * r + k] + 1.0f);
-    if (k == 0)
-        for (int j = r + threadIdx.x; j < lda; j += blockDim.x) inv[j] = 0.f;
+    for (int j = threadIdx.x; j < lda; j += blockDim.x) {
+        float v = j < r ? A[(size_t)k * r + j] : 0.f;
+        if (j == k) v = -1.0f / (v + 1.0f);
+        Ap[(size_t)k * lda + j] = v;
+    }
 }
 
-template <int RPT, int PW>
-__global__ __launch_bounds__(1024) void dict_panel_kernel(int d, int r, int lda,
-                                                          const float* __restrict__ Qt0,
-                                                          const float* __restrict__ Ap,
-                                                          const float* __restrict__ inv_diag,
-                                                          const float* __restrict__ B,
-                                                          const float* __restrict__ Wt,
-                                                          float* __restrict__ WtOut, float* Dt) {
-    static_assert(PW == 16 || PW == 8, "panel width");
+template <int RPT>
+__global__ __launch_bounds__(256) void dict_panel_kernel(int d, int r, int lda,
+                                                         const float* __restrict__ Qt0,
+                                                         const float* __restrict__ Ap,
+                                                         const float* __restrict__ B,
+                                                         const float* __restrict__ Wt,
+                                                         float* __restrict__ WtOut, float* Dt) {
+    constexpr int PW = 16;
     __shared__ __attribute__((aligned(16))) float part[2][16];   // one slot per wave; unused slots stay 0
     const int tid = threadIdx.x;
-    const int wave = tid >> 6;
-    const bool lane0 = (tid & 63) == 0;
+    const int wave = tid >> 6, lane = tid & 63, c16 = lane & 15, g4 = lane >> 4;
+    const bool lane0 = lane == 0;
     if (tid < 32) part[tid >> 4][tid & 15] = 0.f;
     __syncthreads();
     // All [atom][row] arrays go through buffer descriptors: byte address = per-thread row offset +
@@ -169,13 +171,22 @@ __global__ __launch_bounds__(1024) void dict_panel_kernel(int d, int r, int lda,
     const auto rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)Wt, 0, nbytes, 0x00020000);
     const auto rs_o = __builtin_amdgcn_make_buffer_rsrc((void*)WtOut, 0, nbytes, 0x00020000);
     const auto rs_d = __builtin_amdgcn_make_buffer_rsrc((void*)Dt, 0, nbytes, 0x00020000);
-    int voff[RPT];
+    const auto rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)Ap, 0, (unsigned)r * (unsigned)lda * 4u, 0x00020000);
+    const int rowbytes = d * 4;
+    int voff[RPT];            // the thread's own rows: p * 256 + tid
+    int voffB[RPT][4];        // MFMA B operand: row p * 256 + wave * 64 + 16 mt + c16, atom offset g4
 #pragma unroll
     for (int p = 0; p < RPT; ++p) {
-        const int i = tid + p * (int)blockDim.x;
+        const int i = p * 256 + tid;
         voff[p] = i < d ? i * 4 : (int)0x80000000;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int rowb = p * 256 + wave * 64 + 16 * mt + c16;
+            voffB[p][mt] = rowb < d ? (rowb + g4 * d) * 4 : (int)0x80000000;
+        }
     }
-    const int rowbytes = d * 4;
+    const int voffA = (g4 * lda + c16) * 4;
+
     for (int j0 = 0; j0 < r; j0 += PW) {
         float q[RPT][PW], w[RPT][PW];
         // this panel's entries of Q0 - B and of W
@@ -188,108 +199,76 @@ __global__ __launch_bounds__(1024) void dict_panel_kernel(int d, int r, int lda,
                           __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_b, voff[p], so, 0));
                 w[p][n] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_w, voff[p], so, 0));
             }
+            __builtin_amdgcn_sched_barrier(0);           // one row set at a time: 48 loads in flight, not 192
         }
-        if constexpr (RPT == 1 && PW == 16) {
-            // Left-looking update from the atoms before the panel, on the matrix cores (twice the
-            // vector rate for fp32).  Per wave, for its 4 tiles of 16 rows:
-            //     D[atom n][row] += sum_k Ap[k][j0 + n] * Dt[k][row]        (v_mfma_f32_16x16x4_f32)
-            // A operand: lane (g, c) = Ap[k0 + g][j0 + c]; B operand: Dt[k0 + g][tile row c].
-            // D leaves atoms 4g..4g+3 of row c in lane (g, c); a 4x4 transpose between the tile
-            // index and the lane row then hands lane 16g + c all 16 atoms of ITS row (tile g, row c).
-            const int lane = tid & 63, c16 = lane & 15, g4 = lane >> 4;
-            const auto rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)Ap, 0, (unsigned)r * (unsigned)lda * 4u, 0x00020000);
-            const int voffA = (g4 * lda + c16) * 4;
-            int voffB[4];
+        // Left-looking update from the atoms before the panel, on the matrix cores (twice the
+        // vector rate for fp32).  Per wave, for each of its 4 RPT tiles of 16 rows:
+        //     D[atom n][row] += sum_k Ap[k][j0 + n] * Dt[k][row]        (v_mfma_f32_16x16x4_f32)
+        // A operand: lane (g, c) = Ap[k0 + g][j0 + c]; B operand: Dt[k0 + g][tile row c].
+        // D leaves atoms 4g..4g+3 of row c in lane (g, c); a 4x4 transpose between the tile index
+        // and the lane row then hands lane 16g + c all 16 atoms of ITS row (tile g, row c).
+        // Operands are fetched two groups of four atoms ahead (one wave per SIMD: nothing else
+        // covers the L2 latency).
+        {
+            f32x4 D[RPT][4];
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const int rowb = wave * 64 + 16 * mt + c16;
-                voffB[mt] = rowb < d ? (rowb + g4 * d) * 4 : (int)0x80000000;
+            for (int p = 0; p < RPT; ++p)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) D[p][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int ngroups = j0 >> 2;                      // a multiple of 4
+            float a0 = 0.f, a1 = 0.f, b0[RPT][4], b1[RPT][4];
+            auto fetch = [&](int kg, float& a, float (&bv)[RPT][4]) {
+                a = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_a, voffA, (4 * kg * lda + j0) * 4, 0));
+#pragma unroll
+                for (int p = 0; p < RPT; ++p)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+                        bv[p][mt] = __uint_as_float(
+                            __builtin_amdgcn_raw_buffer_load_b32(rs_d, voffB[p][mt], 4 * kg * rowbytes, 0));
+            };
+            auto apply = [&](float a, const float (&bv)[RPT][4]) {
+#pragma unroll
+                for (int p = 0; p < RPT; ++p)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+                        D[p][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[p][mt], D[p][mt], 0, 0, 0);
+            };
+            if (ngroups > 0) {
+                fetch(0, a0, b0);
+                fetch(1, a1, b1);
             }
-            f32x4 D[4];
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) D[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            float an = 0.f, bn[4] = {0.f, 0.f, 0.f, 0.f};
-            if (j0 > 0) {
-                an = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_a, voffA, j0 * 4, 0));
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-                    bn[mt] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_d, voffB[mt], 0, 0));
-            }
-            for (int k0 = 0; k0 < j0; k0 += 4) {
-                const float a = an;
-                float bv[4];
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) bv[mt] = bn[mt];
-                const int kn = min(k0 + 4, j0 - 4);          // last round: fetches its own group again
-                an = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_a, voffA, (kn * lda + j0) * 4, 0));
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-                    bn[mt] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_d, voffB[mt], kn * rowbytes, 0));
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) D[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[mt], D[mt], 0, 0, 0);
+            for (int kg = 0; kg < ngroups; kg += 2) {
+                apply(a0, b0);
+                fetch(min(kg + 2, ngroups - 1), a0, b0);      // past the end: fetches the last group again
+                apply(a1, b1);
+                fetch(min(kg + 3, ngroups - 1), a1, b1);
             }
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                float x0 = D[0][t], x1 = D[1][t], x2 = D[2][t], x3 = D[3][t];
-                xpose4(x0, x1, x2, x3);
-                q[0][t] += x0;
-                q[0][4 + t] += x1;
-                q[0][8 + t] += x2;
-                q[0][12 + t] += x3;
-            }
-        } else {
-            // left-looking update from the atoms before the panel; the deltas of the next four atoms
-            // are fetched while the current four are applied
-            float dn[RPT][4];
-            if (j0 > 0) {
-    #pragma unroll
-                for (int kk = 0; kk < 4; ++kk)
-    #pragma unroll
-                    for (int p = 0; p < RPT; ++p)
-                        dn[p][kk] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_d, voff[p], kk * rowbytes, 0));
-            }
-            for (int k = 0; k < j0; k += 4) {
-                float dl[RPT][4];
-                const int kn = min(k + 4, j0 - 4);           // last round: fetches its own group again
-    #pragma unroll
-                for (int kk = 0; kk < 4; ++kk)
-    #pragma unroll
-                    for (int p = 0; p < RPT; ++p) {
-                        dl[p][kk] = dn[p][kk];
-                        dn[p][kk] = __uint_as_float(
-                            __builtin_amdgcn_raw_buffer_load_b32(rs_d, voff[p], (kn + kk) * rowbytes, 0));
-                    }
-    #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    if (PW == 16) {
-                        const Row16 a = *reinterpret_cast<const Row16*>(Ap + (size_t)(k + kk) * lda + j0);
-    #pragma unroll
-                        for (int n = 0; n < PW; ++n)
-    #pragma unroll
-                            for (int p = 0; p < RPT; ++p) q[p][n] = fmaf(dl[p][kk], a.v[n], q[p][n]);
-                    } else {
-                        const float* __restrict__ a = Ap + (size_t)(k + kk) * lda + j0;
-    #pragma unroll
-                        for (int n = 0; n < PW; ++n)
-    #pragma unroll
-                            for (int p = 0; p < RPT; ++p) q[p][n] = fmaf(dl[p][kk], a[n], q[p][n]);
-                    }
+            for (int p = 0; p < RPT; ++p) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    float x0 = D[p][0][t], x1 = D[p][1][t], x2 = D[p][2][t], x3 = D[p][3][t];
+                    xpose4(x0, x1, x2, x3);
+                    q[p][t] += x0;
+                    q[p][4 + t] += x1;
+                    q[p][8 + t] += x2;
+                    q[p][12 + t] += x3;
                 }
             }
         }
         // The panel's atoms in order (padded atoms j >= r run on zeros of Ap: harmless, not stored).
-        // Every instruction here is paid by all 16 waves on 4 SIMDs, once per atom, in a chain that
-        // nothing overlaps: the norm takes 7 cross-lane steps per wave, one LDS slot per wave, a
-        // barrier that orders LDS traffic only (waiting for the global stores as well, as
-        // __syncthreads would, costs a memory round trip per atom), one LDS read per lane and 5 more
-        // cross-lane steps; 1 / max(1, norm) is one v_rsq_f32.  The row of A for the next atom is
-        // fetched right after the barrier, a whole atom ahead of its use.
-        const Row16 inv16 = *reinterpret_cast<const Row16*>(inv_diag + (j0 & ~15));
-        Row16 acur = *reinterpret_cast<const Row16*>(Ap + (size_t)min(j0, r - 1) * lda + (j0 & ~15));
+        // This chain is what bounds the pass: per atom the norm takes 7 cross-lane steps per wave,
+        // one LDS slot per wave, a barrier that orders LDS traffic only (waiting for the global
+        // stores as well, as __syncthreads would, costs a memory round trip per atom), one LDS read
+        // per lane and 5 more cross-lane steps; 1 / max(1, norm) is one v_rsq_f32.  Four waves (one
+        // per SIMD) run it: every wave repeats the chain, and waves that share a SIMD would take
+        // turns at every one of its steps.  The row of A for the next atom is fetched right after
+        // the barrier, a whole atom ahead of its use.
+        Row16 acur = *reinterpret_cast<const Row16*>(Ap + (size_t)min(j0, r - 1) * lda + j0);
 #pragma unroll
         for (int n = 0; n < PW; ++n) {
             const int j = j0 + n;
-            const float ninv = -inv16.v[(j0 & 15) + n];
+            const float ninv = acur.v[n];                     // diagonal slot: -1 / (A[j][j] + 1)
             float u[RPT];
             float ss = 0.f;
 #pragma unroll
@@ -302,11 +281,10 @@ __global__ __launch_bounds__(1024) void dict_panel_kernel(int d, int r, int lda,
             __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): the LDS write has landed
             __builtin_amdgcn_s_barrier();
             Row16 anext = acur;
-            if (n + 1 < PW)
-                anext = *reinterpret_cast<const Row16*>(Ap + (size_t)min(j + 1, r - 1) * lda + (j0 & ~15));
+            if (n + 1 < PW) anext = *reinterpret_cast<const Row16*>(Ap + (size_t)min(j + 1, r - 1) * lda + j0);
             // the 16 slots, one per lane of a row, summed by the same tree in every wave
             const float total = __builtin_bit_cast(
-                float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, row_total(part[n & 1][tid & 15])), 15));
+                float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, row_total(part[n & 1][c16])), 15));
             const float scale = total > 1.0f ? __builtin_amdgcn_rsqf(total) : 1.0f;
 #pragma unroll
             for (int p = 0; p < RPT; ++p) {
@@ -315,7 +293,8 @@ __global__ __launch_bounds__(1024) void dict_panel_kernel(int d, int r, int lda,
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(wn), rs_o, voff[p], j * rowbytes, 0);
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dv), rs_d, voff[p], j * rowbytes, 0);
 #pragma unroll
-                for (int m = n + 1; m < PW; ++m) q[p][m] = fmaf(acur.v[(j0 & 15) + m], dv, q[p][m]);
+                for (int m = 0; m < PW; ++m)             // (constant bounds: unrolls before n is known)
+                    if (m > n) q[p][m] = fmaf(acur.v[m], dv, q[p][m]);
             }
             acur = anext;
         }
@@ -333,40 +312,36 @@ __global__ void zero_u64_kernel(u64* p, size_t n) {
 int launch_dict_pass(onmf_ctx* c, int d, int r, const float* Win, const float* A, const float* B,
                      float* Wout, hipStream_t s) {
     c->dict_coop_last = false;
-    if ((c->dict_kernel == 2 && d <= 4096) || (c->dict_kernel == 0 && d <= 1024)) {
+    if (d <= 1024 && c->dict_kernel != 1) {
         // Qt0[j][i] = sum_k A[k][j] * W[i][k]
         ONMF_TRY(onmf_reserve(c, c->qt, (size_t)r * d * sizeof(float), "dictionary Qt"));
         float* Qt = (float*)c->qt.p;
         ONMF_TRY(launch_gemm(c, /*a_km=*/true, /*b_kn=*/false, r, d, r, A, r, Win, r, 1.f, 0.f, nullptr,
                              Qt, d, s, &c->slab_side));
         const int lda = (r + 15) / 16 * 16;
-        ONMF_TRY(onmf_reserve(c, c->ddelta, (3 * (size_t)d * r + (size_t)r * lda + lda + 16) * sizeof(float),
+        ONMF_TRY(onmf_reserve(c, c->ddelta, (3 * (size_t)d * r + (size_t)r * lda + 16) * sizeof(float),
                               "dictionary deltas"));
         float* Ap = (float*)c->ddelta.p;             // 64-byte aligned rows
-        float* inv = Ap + (size_t)r * lda;
-        float* Dt = inv + lda;
+        float* Dt = Ap + (size_t)r * lda;
         float* Wt = Dt + (size_t)d * r;              // W^T in, r x d
         float* WtOut = Wt + (size_t)d * r;
         ONMF_TRY(launch_transpose(d, r, Win, Wt, s));
-        hipLaunchKernelGGL(dict_pad_kernel, dim3(r), dim3(64), 0, s, r, lda, A, Ap, inv);
+        hipLaunchKernelGGL(dict_pad_kernel, dim3(r), dim3(64), 0, s, r, lda, A, Ap);
         HIP_TRY(c, hipGetLastError());
-        const int rpt = (d + 1023) / 1024;
-        const int nt = rpt > 1 ? 1024 : (d + 63) / 64 * 64;
-#define PANEL_CASE(RPTV, PWV)                                                                          \
-    hipLaunchKernelGGL((dict_panel_kernel<RPTV, PWV>), dim3(1), dim3(nt), 0, s, d, r, lda, Qt, Ap, inv, B, \
-                       Wt, WtOut, Dt)
-        switch (rpt) {
-            case 1: PANEL_CASE(1, 16); break;
-            case 2: PANEL_CASE(2, 16); break;
-            case 3: PANEL_CASE(3, 8); break;
-            default: PANEL_CASE(4, 8); break;
-        }
+        // 256 threads, thread t owns rows t, t + 256, ...
+        const int rpt = (d + 255) / 256;
+        const int nt = rpt > 1 ? 256 : (d + 63) / 64 * 64;
+#define PANEL_CASE(RPTV)                                                                              \
+    hipLaunchKernelGGL((dict_panel_kernel<RPTV>), dim3(1), dim3(nt), 0, s, d, r, lda, Qt, Ap, B, Wt, WtOut, Dt)
+        if (rpt <= 1) PANEL_CASE(1);
+        else if (rpt <= 2) PANEL_CASE(2);
+        else PANEL_CASE(4);
 #undef PANEL_CASE
         HIP_TRY(c, hipGetLastError());
         return launch_transpose(r, d, WtOut, Wout, s);
     }
     if (c->dict_kernel == 2)
-        return onmf_fail(c, ONMF_ERR_ARG, "update_dict: the one-workgroup kernel covers d <= 4096 (d=%d)", d);
+        return onmf_fail(c, ONMF_ERR_ARG, "update_dict: the one-workgroup kernel covers d <= 1024 (d=%d)", d);
     c->dict_coop_last = true;
     const int nwg = (d + 63) / 64;
     if (nwg > 256)

@@ -322,7 +322,7 @@ int launch_gemm(onmf_ctx* c, bool a_km, bool b_kn, int M, int N, int K, const fl
     int splits = 1;
     if (tiles < 256 && ktiles >= 16) {
         splits = (512 + tiles - 1) / tiles;
-        const int max_by_k = ktiles / 8;          // at least 8 k-tiles of work per slab
+        const int max_by_k = ktiles / 2;          // at least 2 k-tiles of work per slab
         if (splits > max_by_k) splits = max_by_k;
         if (splits < 1) splits = 1;
     }

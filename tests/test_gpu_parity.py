@@ -291,10 +291,19 @@ def test_step_against_oracle(eng, orc, d, r, b, kernel):
 
 
 @pytest.mark.parametrize("kernel", [1, 2])
-@pytest.mark.parametrize("shape", [(1500, 48), (64, 16), (1024, 256), (2500, 40), (4096, 23), (33, 7)])
+@pytest.mark.parametrize("shape", [(1500, 48), (64, 16), (1024, 256), (2500, 40), (700, 23), (300, 100), (33, 7)])
 def test_update_dict_both_kernels(eng, orc, kernel, shape):
     """The dictionary pass with cooperating workgroups (1; d = 1500 -> 24 of them) and inside one
-    workgroup (2; one to four rows per thread, panels of 16 or 8 atoms), against the oracle."""
+    workgroup (2; d <= 1024, one to four rows per thread), against the oracle."""
+    if kernel == 2 and shape[0] > 1024:
+        with pytest.raises(Exception):
+            eng.set_option(6, 2)
+            try:
+                eng.update_dict(eng.zeros(shape[0], shape[1]), eng.zeros(shape[1], shape[1]),
+                                eng.zeros(shape[1], shape[0]))
+            finally:
+                eng.set_option(6, 0)
+        return
     d, r = shape
     rs = np.random.RandomState(77 + d)
     W = rs.rand(d, r)
