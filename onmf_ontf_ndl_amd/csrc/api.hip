@@ -321,20 +321,23 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
         // "stop"/"inconclusive" verdict return at once and leave both code buffers untouched.
         ONMF_TRY(onmf_reserve(c, c->screen, (size_t)ScreenLayout::TOTAL * sizeof(float), "stop-test screen"));
         float* base = (float*)c->screen.p;
-        const ScreenDev sc = screen_pointers(base);
         ONMF_TRY(launch_screen_init(c, base, r, s));
         int start = 0;
         while (start < sub_iter) {
             for (int i = start; i < sub_iter; ++i) {
                 const float damp = (float)std::sqrt((double)i + 10.0);
                 int groups = 0;
+                // sweep i evaluates sweep i-1's test in its prologue (not the first one launched
+                // here: there is none before sweep 0, and the host settled the one before a relaunch)
+                const ScreenDev sc = {base, i, i == start ? 1 : 0, (float)tol, (float)rank_cap};
                 ONMF_TRY(profile_mark(c, s));
                 ONMF_TRY(launch_sweep(c, r, b, Gm, Cm, buf[i & 1], buf[(i + 1) & 1], alpha, damp, 0,
                                       (double*)c->stats.p, &groups, s, &sc));
                 ONMF_TRY(profile_mark(c, s));
-                ONMF_TRY(launch_screen_refresh(c, base, r, b, buf[(i + 1) & 1], buf[i & 1], s));
-                ONMF_TRY(launch_screen_decide(c, base, r, i, (float)tol, (float)rank_cap, s));
+                // one power step of the probe subspace per solve, on the first sweep's move
+                if (i == 0) ONMF_TRY(launch_screen_refresh(c, base, r, b, buf[1], buf[0], s));
             }
+            ONMF_TRY(launch_screen_final(c, base, sub_iter - 1, (float)tol, (float)rank_cap, s));
             HIP_TRY(c, hipMemcpyAsync(c->pinned, base + ScreenLayout::REC,
                                       (size_t)4 * SCREEN_MAX_SWEEPS * sizeof(float), hipMemcpyDeviceToHost, s));
             HIP_TRY(c, hipStreamSynchronize(s));

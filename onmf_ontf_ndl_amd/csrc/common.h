@@ -83,15 +83,14 @@ int launch_gemm(onmf_ctx* c, bool a_km, bool b_kn, int M, int N, int K, const fl
                 const float* B, int ldb, float alpha, float beta, const float* Cin, float* C,
                 int ldc, hipStream_t s, DevBuf* slab = nullptr);
 
-// Device pointers of the stopping-test screen (screen.hip); all inside one allocation.
+// What a probing sweep needs of the stopping-test screen (screen.hip): the state block and its
+// own position in the solve.
 struct ScreenDev {
-    const float* ublk;   // NB swizzled 16x16 blocks of U^T (16 unit probe vectors, r_pad long)
-    const float* v;      // r_pad: positive vector of the Collatz-Wielandt bound
-    float* zacc;         // ZREPL x r_pad x 16: power-step accumulator
-    float* p2acc;        // REPL x 16: probe energies
-    float* yacc;         // REPL x 256: H (H^T v)
-    double* sums;        // REPL x {sum (H_new - H_old)^2, sum H_old^2}
-    const int* flag;     // 0 = keep sweeping
+    float* base;         // ScreenLayout
+    int k;               // index of this sweep in the solve
+    int skip_verdict;    // != 0: do not evaluate the previous sweep's test (first sweep, or the host did)
+    float tol;           // stopping_diff
+    float rank_cap;      // min(r, b)
 };
 
 // One Gauss-Seidel sweep over all rows: Hout = sweep(Hin).  stats (device, 2 doubles per
@@ -107,30 +106,63 @@ int launch_sweep(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm, co
                  hipStream_t s, const ScreenDev* screen = nullptr);
 bool sweep_tile_covers(int r, int b);
 
-// Stopping-test screen: state layout, initialisation and the per-sweep decision kernel.
+// Stopping-test screen: state layout and kernels.
 constexpr int SCREEN_MAX_SWEEPS = 64;
 constexpr int SCREEN_REPL = 8;       // replicas of the sweep kernel's accumulators (atomic contention)
 constexpr int SCREEN_ZREPL = 4;      // replicas of the power-step accumulator
 struct ScreenLayout {           // offsets in floats into ctx->screen
-    static constexpr int UBLK = 0;                                 // 16 * 256
-    static constexpr int V = 4096;                                 // 256
-    static constexpr int ZACC = V + 256;                           // ZREPL x 256 x 16
-    static constexpr int P2ACC = ZACC + SCREEN_ZREPL * 4096;       // REPL x 16
-    static constexpr int YACC = P2ACC + SCREEN_REPL * 16;          // REPL x 256
-    static constexpr int SUMS = YACC + SCREEN_REPL * 256;          // REPL x 2 doubles (8-byte aligned)
-    static constexpr int FLAG = SUMS + SCREEN_REPL * 4;            // int
-    static constexpr int UBPREV = FLAG + 1;        // float: upper bound of sigma_max(H before the sweep)
-    static constexpr int SKIP = FLAG + 2;          // int: the next sweep's probe power step is skipped
-    static constexpr int AVEC = FLAG + 4;          // 16: last Ritz coefficient vector (warm start)
+    static constexpr int UBLK = 0;                                 // 16 * 256: probe blocks
+    static constexpr int V = 4096;                                 // 2 x 256: sweep k reads V + (k & 1) * 256
+    static constexpr int ZACC = V + 512;                           // ZREPL x 256 x 16
+    // three accumulator sets; sweep k adds into set k % 3, reads set (k - 1) % 3, clears set (k + 1) % 3
+    static constexpr int SETS = ZACC + SCREEN_ZREPL * 4096;
+    static constexpr int SET_P2 = 0;                               // REPL x 16 probe energies
+    static constexpr int SET_Y = SCREEN_REPL * 16;                 // REPL x 256: H (H^T v)
+    static constexpr int SET_SUMS = SET_Y + SCREEN_REPL * 256;     // REPL x 2 doubles
+    static constexpr int SETSZ = SET_SUMS + SCREEN_REPL * 4;
+    static constexpr int UBH = SETS + 3 * SETSZ;   // MAX_SWEEPS + 1: bound of sigma_max(H before sweep k)
+    static constexpr int FLAG = UBH + SCREEN_MAX_SWEEPS + 1;       // int: 0 = keep sweeping
+    static constexpr int AVEC = FLAG + 1;          // 16: last Ritz coefficient vector (warm start)
     static constexpr int REC = AVEC + 16;          // SCREEN_MAX_SWEEPS x 4 floats
     static constexpr int TOTAL = REC + 4 * SCREEN_MAX_SWEEPS;
 };
-static_assert(ScreenLayout::SUMS % 2 == 0, "double alignment");
-ScreenDev screen_pointers(float* base);
+static_assert(ScreenLayout::SETS % 2 == 0 && ScreenLayout::SETSZ % 2 == 0 && ScreenLayout::SET_SUMS % 2 == 0,
+              "double alignment");
+
+#if defined(__HIPCC__)
+// The three-way verdict of one sweep from its by-products (see screen.hip).  Deterministic: every
+// caller that feeds it the same numbers gets the same answer.  0 continue, 1 stop, 2 inconclusive.
+__device__ __forceinline__ int screen_verdict(float lb2, double dsum, double hsum, float ubp, float tol,
+                                              float rank_cap, float& lower_f, float& upper_f, float& ubh_f) {
+    const double fD = sqrt(dsum), fH = sqrt(hsum);
+    double ubH = fH * (1.0 + 1e-5);                       // sigma_max <= Frobenius norm
+    if (ubp > 0.f && (double)ubp < ubH) ubH = ubp;
+    int verdict;
+    double lower = 0.0, upper = 1e300;
+    if (hsum == 0.0) {            // dist = 0/0 (NaN: loop ends) or x/0 (+inf: continues)
+        verdict = (dsum == 0.0) ? 1 : 0;
+        lower = upper = (dsum == 0.0) ? 0.0 : 1e300;
+    } else if (dsum == 0.0) {     // dist = 0
+        verdict = (0.0 > (double)tol) ? 0 : 1;
+        lower = upper = 0.0;
+    } else {
+        const double lbs = fmax(sqrt((double)lb2) * (1.0 - 2e-4), fD / sqrt((double)rank_cap) * (1.0 - 1e-4));
+        lower = lbs / ubH;
+        upper = fD * (1.0 + 1e-4) / (fH / sqrt((double)rank_cap));
+        verdict = (lower > (double)tol) ? 0 : ((upper <= (double)tol) ? 1 : 2);
+    }
+    lower_f = (float)lower;
+    upper_f = (float)fmin(upper, 3.0e38);
+    ubh_f = (float)ubH;
+    return verdict;
+}
+#endif
+
 int launch_screen_init(onmf_ctx* c, float* base, int r, hipStream_t s);
-int launch_screen_decide(onmf_ctx* c, float* base, int r, int sweep_index, float tol, float rank_cap,
-                         hipStream_t s);
+// verdict of sweep k_last (the last one enqueued), which no later sweep evaluates
+int launch_screen_final(onmf_ctx* c, float* base, int k_last, float tol, float rank_cap, hipStream_t s);
 int launch_screen_clear_flag(onmf_ctx* c, float* base, hipStream_t s);
+// one power step of the probe subspace on a sample of columns, then the probe update
 int launch_screen_refresh(onmf_ctx* c, float* base, int r, int b, const float* Hnew, const float* Hold,
                           hipStream_t s);
 

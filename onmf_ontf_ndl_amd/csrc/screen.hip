@@ -5,7 +5,8 @@
 //     lb2  = max_p || u_p^T (H_new - H_old) ||^2     for 16 unit probe vectors u_p   (<= sigma_max^2)
 //     cw   = max_k y_k / v_k,  y = H (H^T v), v > 0   (Collatz-Wielandt: >= sigma_max(H)^2, because
 //                                                      H H^T is entrywise nonnegative)
-// and this file's one-workgroup kernel turns them into a three-way verdict per sweep:
+// and screen_verdict() turns them into a three-way verdict per sweep, evaluated by the NEXT sweep's
+// workgroups in their prologue (the last sweep's by a small kernel of this file):
 //     lower bound of dist > tol  -> keep sweeping (certain)
 //     upper bound of dist <= tol -> stop (certain)
 //     otherwise                  -> inconclusive: the host evaluates the test in full
@@ -33,16 +34,15 @@ __global__ __launch_bounds__(256) void screen_init_kernel(float* base, int r, in
     const int first = keep_probes ? ScreenLayout::V : 0;
     for (int e = first + tid; e < ScreenLayout::TOTAL; e += 256) base[e] = 0.f;
     __syncthreads();
-    if (tid < r) base[ScreenLayout::V + tid] = 1.0f;
+    base[ScreenLayout::V + tid] = 1.0f;
+    base[ScreenLayout::V + 256 + tid] = 1.0f;
+    if (tid <= SCREEN_MAX_SWEEPS) base[ScreenLayout::UBH + tid] = -1.0f;     // no bound known
     if (tid < r && !keep_probes) {
         const int K = tid >> 4, j = tid & 15;
         for (int p = 0; p < 16; ++p)
             base[ScreenLayout::UBLK + K * 256 + blk_off(p, j)] = scale * hash_unit(tid * 16 + p + 1);
     }
-    if (tid == 0) {
-        base[ScreenLayout::UBPREV] = -1.0f;
-        base[ScreenLayout::AVEC] = 1.0f;
-    }
+    if (tid == 0) base[ScreenLayout::AVEC] = 1.0f;
 }
 
 __global__ void screen_clear_flag_kernel(float* base) {
@@ -66,7 +66,6 @@ __global__ __launch_bounds__(256) void screen_refresh_kernel(int r, int b, int s
     __shared__ float sd[4][16 * 17];
     __shared__ float sp[16 * 17];
     if (reinterpret_cast<const int*>(base)[ScreenLayout::FLAG] != 0) return;
-    if (reinterpret_cast<const int*>(base)[ScreenLayout::SKIP] != 0) return;   // probes good enough (uniform)
     const float* ublk = base + ScreenLayout::UBLK;
     float* zacc = base + ScreenLayout::ZACC + (blockIdx.x % SCREEN_ZREPL) * 4096;
     const int tid = threadIdx.x;
@@ -136,40 +135,50 @@ int run_refresh(onmf_ctx* c, int r, int b, const float* Hnew, const float* Hold,
     return ONMF_OK;
 }
 
-__device__ __forceinline__ float block_max(float v, float* red) {
+// Verdict of sweep k, for the sweep that no later sweep follows (one wave).
+__global__ __launch_bounds__(64) void screen_final_kernel(float* base, int k, float tol, float rank_cap) {
+    int* flagp = reinterpret_cast<int*>(base) + ScreenLayout::FLAG;
+    if (*flagp != 0) return;                                  // the loop ended earlier (uniform)
     const int tid = threadIdx.x;
+    const float* set = base + ScreenLayout::SETS + (k % 3) * ScreenLayout::SETSZ;
+    float e = 0.f;
+    if (tid < 16)
+        for (int rp = 0; rp < SCREEN_REPL; ++rp) e += set[ScreenLayout::SET_P2 + rp * 16 + tid];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
-    __syncthreads();
-    if ((tid & 63) == 0) red[tid >> 6] = v;
-    __syncthreads();
-    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    for (int off = 8; off > 0; off >>= 1) e = fmaxf(e, __shfl_xor(e, off));
+    if (tid == 0) {
+        const double* sums = reinterpret_cast<const double*>(set + ScreenLayout::SET_SUMS);
+        double dsum = 0.0, hsum = 0.0;
+        for (int rp = 0; rp < SCREEN_REPL; ++rp) {
+            dsum += sums[2 * rp];
+            hsum += sums[2 * rp + 1];
+        }
+        float lower, upper, ubh;
+        const int verdict = screen_verdict(e, dsum, hsum, base[ScreenLayout::UBH + k], tol, rank_cap, lower,
+                                           upper, ubh);
+        float* rec = base + ScreenLayout::REC + 4 * k;
+        rec[0] = lower;
+        rec[1] = upper;
+        rec[2] = (float)(verdict + 1);
+        rec[3] = ubh;
+        if (verdict != 0) *flagp = verdict;
+    }
 }
 
-// One workgroup of 256 threads; thread k owns row k of the r_pad <= 256 rows.
-__global__ __launch_bounds__(256) void screen_decide_kernel(float* base, int r, int sweep_index,
-                                                            float tol, float rank_cap) {
+// Probe update after a power step: one workgroup of 256 threads; thread k owns row k of the
+// r_pad <= 256 rows of Z.
+__global__ __launch_bounds__(256) void screen_probe_update_kernel(float* base, int r) {
     __shared__ float Z[256 * 17];
     __shared__ float M[16 * 16];      // Z^T Z
-    __shared__ float avec[16], mvec[16], nrm[16], red[4];
-    __shared__ int entry_s, skip_s;
-    int* flagp = reinterpret_cast<int*>(base) + ScreenLayout::FLAG;
-    int* skipp = reinterpret_cast<int*>(base) + ScreenLayout::SKIP;
+    __shared__ float avec[16], mvec[16], nrm[16];
     const int tid = threadIdx.x;
-    if (tid == 0) {
-        entry_s = *flagp;
-        skip_s = *skipp;
-    }
-    __syncthreads();
-    if (entry_s != 0) return;                                 // loop already ended (uniform exit)
-    const bool refreshed = skip_s == 0;                       // the power step ran after this sweep
-    float* vvec = base + ScreenLayout::V;
+    if (reinterpret_cast<const int*>(base)[ScreenLayout::FLAG] != 0) return;   // uniform
 
-    // ---- gather the replicated accumulators (and clear them for the next sweep) ----
+    // ---- gather the replicated accumulator (and clear it for the next power step) ----
     float zrow[16];
 #pragma unroll
     for (int p = 0; p < 16; ++p) zrow[p] = 0.f;
-    for (int rep = 0; rep < (refreshed ? SCREEN_ZREPL : 0); ++rep) {
+    for (int rep = 0; rep < SCREEN_ZREPL; ++rep) {
         float4* zp = reinterpret_cast<float4*>(base + ScreenLayout::ZACC + rep * 4096 + tid * 16);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -178,78 +187,14 @@ __global__ __launch_bounds__(256) void screen_decide_kernel(float* base, int r, 
             zp[q] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
-    float yk = 0.f;
-    for (int rep = 0; rep < SCREEN_REPL; ++rep) {
-        float* yp = base + ScreenLayout::YACC + rep * 256 + tid;
-        yk += *yp;
-        *yp = 0.f;
-    }
     if (tid >= r) {
-        yk = 0.f;
 #pragma unroll
         for (int p = 0; p < 16; ++p) zrow[p] = 0.f;
     }
 #pragma unroll
     for (int p = 0; p < 16; ++p) Z[tid * 17 + p] = zrow[p];
+    __syncthreads();
 
-    // ---- verdict for this sweep (thread 0) ----
-    if (tid == 0) {
-        double dsum = 0.0, hsum = 0.0;
-        double* sums = reinterpret_cast<double*>(base + ScreenLayout::SUMS);
-        for (int rep = 0; rep < SCREEN_REPL; ++rep) {
-            dsum += sums[2 * rep];
-            hsum += sums[2 * rep + 1];
-            sums[2 * rep] = 0.0;
-            sums[2 * rep + 1] = 0.0;
-        }
-        float lb2 = 0.f;
-        for (int p = 0; p < 16; ++p) {
-            float e = 0.f;
-            for (int rep = 0; rep < SCREEN_REPL; ++rep) {
-                e += base[ScreenLayout::P2ACC + rep * 16 + p];
-                base[ScreenLayout::P2ACC + rep * 16 + p] = 0.f;
-            }
-            lb2 = fmaxf(lb2, e);
-        }
-        const double fD = sqrt(dsum), fH = sqrt(hsum);
-        const float ubp = base[ScreenLayout::UBPREV];
-        double ubH = fH * (1.0 + 1e-5);                       // sigma_max <= Frobenius norm
-        if (ubp > 0.f && (double)ubp < ubH) ubH = ubp;
-        int verdict;                                          // 0 continue, 1 stop, 2 inconclusive
-        double lower = 0.0, upper = 1e300;
-        if (hsum == 0.0) {            // dist = 0/0 (NaN: loop ends) or x/0 (+inf: continues)
-            verdict = (dsum == 0.0) ? 1 : 0;
-            lower = upper = (dsum == 0.0) ? 0.0 : 1e300;
-        } else if (dsum == 0.0) {     // dist = 0
-            verdict = (0.0 > (double)tol) ? 0 : 1;
-            lower = upper = 0.0;
-        } else {
-            const double lbs = fmax(sqrt((double)lb2) * (1.0 - 2e-4), fD / sqrt((double)rank_cap) * (1.0 - 1e-4));
-            lower = lbs / ubH;
-            upper = fD * (1.0 + 1e-4) / (fH / sqrt((double)rank_cap));
-            verdict = (lower > (double)tol) ? 0 : ((upper <= (double)tol) ? 1 : 2);
-        }
-        float* rec = base + ScreenLayout::REC + 4 * sweep_index;
-        rec[0] = (float)lower;
-        rec[1] = (float)fmin(upper, 3.0e38);
-        rec[2] = (float)(verdict + 1);                        // 0 = sweep did not run
-        rec[3] = (float)ubH;                                  // upper bound of sigma_max(H before the sweep)
-        if (verdict != 0) *flagp = verdict;
-        // A lower bound well above the tolerance needs no better probes: the next sweep skips the
-        // power step (and this kernel the probe update) until the margin shrinks.
-        *skipp = (verdict == 0 && lower > 1.5 * (double)tol) ? 1 : 0;
-    }
-
-    // ---- Collatz-Wielandt bound of sigma_max(H_new) for the next sweep's test, next v ----
-    const float vk = (tid < r) ? vvec[tid] : 1.f;
-    const float ratio = (tid < r) ? yk / vk : 0.f;            // v > 0 by construction
-    const float cw = block_max(ratio, red);
-    const float ymax = block_max(yk, red);                    // (its barriers also publish Z)
-    if (tid == 0) base[ScreenLayout::UBPREV] = (cw > 0.f) ? sqrtf(cw) * (1.0f + 2e-4f) : -1.0f;
-    if (tid < r) vvec[tid] = (ymax > 0.f) ? (yk / ymax + 1e-3f) : 1.0f;
-    if (!refreshed) return;                                   // uniform: keep the probes as they are
-
-    // ---- refresh the probes ----
     // M = Z^T Z; a = its top eigenvector (a few power steps); t = Z a is the dominant direction of
     // the power-stepped subspace.  New probes: t, and Z_0..Z_14 with their component along t
     // removed; each column is then scaled by its measured norm, so every probe is a unit vector
@@ -295,7 +240,7 @@ __global__ __launch_bounds__(256) void screen_decide_kernel(float* base, int r, 
         if (tid < 16) {
             avec[tid] = a;
             mvec[tid] = (tt > 0.f) ? m / tt : 0.f;            // c_q = (t^T Z_q) / (t^T t)
-            base[ScreenLayout::AVEC + tid] = (tid == 0) ? 1.f : 0.f;   // next sweep: probe 0 is the top one
+            base[ScreenLayout::AVEC + tid] = (tid == 0) ? 1.f : 0.f;   // next time: probe 0 is the top one
         }
     }
     __syncthreads();
@@ -334,18 +279,6 @@ __global__ __launch_bounds__(256) void screen_decide_kernel(float* base, int r, 
 
 }  // namespace
 
-ScreenDev screen_pointers(float* base) {
-    ScreenDev sc;
-    sc.ublk = base + ScreenLayout::UBLK;
-    sc.v = base + ScreenLayout::V;
-    sc.zacc = base + ScreenLayout::ZACC;
-    sc.p2acc = base + ScreenLayout::P2ACC;
-    sc.yacc = base + ScreenLayout::YACC;
-    sc.sums = reinterpret_cast<double*>(base + ScreenLayout::SUMS);
-    sc.flag = reinterpret_cast<const int*>(base) + ScreenLayout::FLAG;
-    return sc;
-}
-
 int launch_screen_init(onmf_ctx* c, float* base, int r, hipStream_t s) {
     const int keep = (c->screen_r == r) ? 1 : 0;
     c->screen_r = r;
@@ -354,22 +287,26 @@ int launch_screen_init(onmf_ctx* c, float* base, int r, hipStream_t s) {
     return ONMF_OK;
 }
 
-int launch_screen_decide(onmf_ctx* c, float* base, int r, int sweep_index, float tol, float rank_cap,
-                         hipStream_t s) {
-    hipLaunchKernelGGL(screen_decide_kernel, dim3(1), dim3(256), 0, s, base, r, sweep_index, tol, rank_cap);
+int launch_screen_final(onmf_ctx* c, float* base, int k_last, float tol, float rank_cap, hipStream_t s) {
+    hipLaunchKernelGGL(screen_final_kernel, dim3(1), dim3(64), 0, s, base, k_last, tol, rank_cap);
     HIP_TRY(c, hipGetLastError());
     return ONMF_OK;
 }
 
 int launch_screen_refresh(onmf_ctx* c, float* base, int r, int b, const float* Hnew, const float* Hold,
                           hipStream_t s) {
+    int rc = ONMF_ERR_ARG;
     switch ((r + 15) / 16) {
-#define RCASE(N) case N: return run_refresh<N>(c, r, b, Hnew, Hold, base, s)
+#define RCASE(N) case N: rc = run_refresh<N>(c, r, b, Hnew, Hold, base, s); break
         RCASE(1); RCASE(2); RCASE(3); RCASE(4); RCASE(5); RCASE(6); RCASE(7); RCASE(8);
         RCASE(9); RCASE(10); RCASE(11); RCASE(12); RCASE(13); RCASE(14); RCASE(15); RCASE(16);
 #undef RCASE
+        default: return onmf_fail(c, ONMF_ERR_ARG, "screen refresh: unsupported r=%d", r);
     }
-    return onmf_fail(c, ONMF_ERR_ARG, "screen refresh: unsupported r=%d", r);
+    if (rc != ONMF_OK) return rc;
+    hipLaunchKernelGGL(screen_probe_update_kernel, dim3(1), dim3(256), 0, s, base, r);
+    HIP_TRY(c, hipGetLastError());
+    return ONMF_OK;
 }
 
 int launch_screen_clear_flag(onmf_ctx* c, float* base, hipStream_t s) {

@@ -77,10 +77,13 @@ __global__ __launch_bounds__(1024 / CT) void sweep_tile_kernel(
     float* ywg = vs + 16 * NB;             // PROBE: workgroup partial of y
     float* p2wg = ywg + 16 * NB;           // PROBE: workgroup partial of the 16 probe energies
     double* sumwg = reinterpret_cast<double*>(p2wg + 16);   // PROBE: workgroup partial of the two sums
+    float* redwg = p2wg + 20;              // PROBE: 32 floats of reduction scratch
+    int* verdict_s = reinterpret_cast<int*>(p2wg + 52);     // PROBE: the previous sweep's verdict
 
     const int tid = threadIdx.x;
     if (PROBE) {
-        if (*sc.flag != 0) return;         // an earlier sweep's test ended the loop (grid-uniform)
+        // an earlier sweep's test ended the loop (grid-uniform)
+        if (reinterpret_cast<const int*>(sc.base)[ScreenLayout::FLAG] != 0) return;
     }
 
     // ---- stage Gm into LDS (whole workgroup): one float4 (4 consecutive columns of one row of a
@@ -137,16 +140,87 @@ __global__ __launch_bounds__(1024 / CT) void sweep_tile_kernel(
         }
         steps[k] = st;
         if (PROBE) {
-            vs[k] = sc.v[k];
+            vs[k] = sc.base[ScreenLayout::V + (sc.k & 1) * 256 + k];
             ywg[k] = 0.f;
         }
     }
     if (PROBE) {
-        for (int e = tid; e < NB * 256; e += NT) Us[e] = sc.ublk[e];
+        for (int e = tid; e < NB * 256; e += NT) Us[e] = sc.base[ScreenLayout::UBLK + e];
         if (tid < 16) p2wg[tid] = 0.f;
         if (tid < 2) sumwg[tid] = 0.0;
+        // The previous sweep's stopping test, from the by-products it left in its accumulator set.
+        // Every workgroup evaluates it (same numbers, same arithmetic, same answer) instead of
+        // waiting for a kernel of its own between two sweeps; workgroup 0 records it.
+        if (tid < 64) {
+            int verdict = 0;
+            if (!sc.skip_verdict) {
+                const float* prev = sc.base + ScreenLayout::SETS + ((sc.k + 2) % 3) * ScreenLayout::SETSZ;
+                float e = 0.f;
+                if (tid < 16)
+                    for (int rp = 0; rp < SCREEN_REPL; ++rp) e += prev[ScreenLayout::SET_P2 + rp * 16 + tid];
+#pragma unroll
+                for (int off = 8; off > 0; off >>= 1) e = fmaxf(e, __shfl_xor(e, off));
+                if (tid == 0) {
+                    const double* sums = reinterpret_cast<const double*>(prev + ScreenLayout::SET_SUMS);
+                    double dsum = 0.0, hsum = 0.0;
+                    for (int rp = 0; rp < SCREEN_REPL; ++rp) {
+                        dsum += sums[2 * rp];
+                        hsum += sums[2 * rp + 1];
+                    }
+                    float lower, upper, ubh;
+                    verdict = screen_verdict(e, dsum, hsum, sc.base[ScreenLayout::UBH + sc.k - 1], sc.tol,
+                                             sc.rank_cap, lower, upper, ubh);
+                    if (blockIdx.x == 0) {
+                        float* rec = sc.base + ScreenLayout::REC + 4 * (sc.k - 1);
+                        rec[0] = lower;
+                        rec[1] = upper;
+                        rec[2] = (float)(verdict + 1);        // 0 = no verdict yet
+                        rec[3] = ubh;
+                        if (verdict != 0) reinterpret_cast<int*>(sc.base)[ScreenLayout::FLAG] = verdict;
+                    }
+                }
+            }
+            if (tid == 0) *verdict_s = verdict;
+        }
     }
     __syncthreads();
+    if (PROBE) {
+        if (*verdict_s != 0) return;       // workgroup-uniform, and the same in every workgroup
+        if (blockIdx.x == 0) {
+            // Housekeeping of workgroup 0, for the sweeps to come: the Collatz-Wielandt bound of
+            // sigma_max(H before this sweep) from the previous sweep's y = H (H^T v), the vector v
+            // of the next sweep, and a clean accumulator set for it.
+            float* nxt_v = sc.base + ScreenLayout::V + ((sc.k + 1) & 1) * 256;   // also v of sweep k - 1
+            if (sc.k > 0) {
+                const float* prev = sc.base + ScreenLayout::SETS + ((sc.k + 2) % 3) * ScreenLayout::SETSZ;
+                float yk = 0.f, ratio = 0.f;
+                if (tid < r) {
+                    for (int rp = 0; rp < SCREEN_REPL; ++rp) yk += prev[ScreenLayout::SET_Y + rp * 256 + tid];
+                    ratio = yk / nxt_v[tid];                  // v > 0 by construction
+                }
+                float m0 = ratio, m1 = yk;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    m0 = fmaxf(m0, __shfl_xor(m0, off));
+                    m1 = fmaxf(m1, __shfl_xor(m1, off));
+                }
+                if ((tid & 63) == 0) {
+                    redwg[tid >> 6] = m0;
+                    redwg[16 + (tid >> 6)] = m1;
+                }
+                __syncthreads();
+                float cw = 0.f, ymax = 0.f;
+                for (int wv = 0; wv < WAVES; ++wv) {
+                    cw = fmaxf(cw, redwg[wv]);
+                    ymax = fmaxf(ymax, redwg[16 + wv]);
+                }
+                if (tid == 0) sc.base[ScreenLayout::UBH + sc.k] = (cw > 0.f) ? sqrtf(cw) * (1.0f + 2e-4f) : -1.0f;
+                if (tid < r) nxt_v[tid] = (ymax > 0.f) ? (yk / ymax + 1e-3f) : 1.0f;
+            }
+            float* nxt = sc.base + ScreenLayout::SETS + ((sc.k + 1) % 3) * ScreenLayout::SETSZ;
+            for (int e = tid; e < ScreenLayout::SETSZ; e += NT) nxt[e] = 0.f;
+        }
+    }
 
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -398,9 +472,10 @@ __global__ __launch_bounds__(1024 / CT) void sweep_tile_kernel(
         __syncthreads();
         // one set of global atomics per workgroup, spread over replicas to keep contention low
         const int rep = blockIdx.x % SCREEN_REPL;
-        for (int k = tid; k < 16 * NB; k += NT) atomicAdd(&sc.yacc[rep * 256 + k], ywg[k]);
-        if (tid < 16) atomicAdd(&sc.p2acc[rep * 16 + tid], p2wg[tid]);
-        if (tid < 2) atomicAdd(&sc.sums[rep * 2 + tid], sumwg[tid]);
+        float* cur = sc.base + ScreenLayout::SETS + (sc.k % 3) * ScreenLayout::SETSZ;
+        for (int k = tid; k < 16 * NB; k += NT) atomicAdd(&cur[ScreenLayout::SET_Y + rep * 256 + k], ywg[k]);
+        if (tid < 16) atomicAdd(&cur[ScreenLayout::SET_P2 + rep * 16 + tid], p2wg[tid]);
+        if (tid < 2) atomicAdd(reinterpret_cast<double*>(cur + ScreenLayout::SET_SUMS) + rep * 2 + tid, sumwg[tid]);
     }
 }
 
@@ -410,7 +485,7 @@ int run_tile(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm, const 
              hipStream_t s) {
     constexpr int NBLK = HALF ? NB * (NB + 1) / 2 : NB * NB;
     constexpr size_t lds = sizeof(float) * ((size_t)NBLK * 256 + NB * 16 +
-                                            (PROBE ? (NB * 256 + 2 * NB * 16 + 16 + 4) : 0));
+                                            (PROBE ? (NB * 256 + 2 * NB * 16 + 16 + 4 + 32 + 4) : 0));
     static_assert(lds <= 160 * 1024, "Gm blocks do not fit the LDS");
     static bool attr_done = false;
     if (!attr_done) {
