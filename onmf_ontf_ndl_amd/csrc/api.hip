@@ -321,7 +321,10 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
         // "stop"/"inconclusive" verdict return at once and leave both code buffers untouched.
         ONMF_TRY(onmf_reserve(c, c->screen, (size_t)ScreenLayout::TOTAL * sizeof(float), "stop-test screen"));
         float* base = (float*)c->screen.p;
+        const bool refresh_probes = c->screen_refresh_due || c->screen_r != r;
         ONMF_TRY(launch_screen_init(c, base, r, s));
+        double min_margin = 1e300;       // smallest (lower bound / tol) among the "continue" verdicts
+        bool undecided = false;
         int start = 0;
         while (start < sub_iter) {
             for (int i = start; i < sub_iter; ++i) {
@@ -334,8 +337,9 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
                 ONMF_TRY(launch_sweep(c, r, b, Gm, Cm, buf[i & 1], buf[(i + 1) & 1], alpha, damp, 0,
                                       (double*)c->stats.p, &groups, s, &sc));
                 ONMF_TRY(profile_mark(c, s));
-                // one power step of the probe subspace per solve, on the first sweep's move
-                if (i == 0) ONMF_TRY(launch_screen_refresh(c, base, r, b, buf[1], buf[0], s));
+                // a power step of the probe subspace on the first sweep's move, when the probes kept
+                // from the previous solve left little margin (or there are none yet)
+                if (i == 0 && refresh_probes) ONMF_TRY(launch_screen_refresh(c, base, r, b, buf[1], buf[0], s));
             }
             ONMF_TRY(launch_screen_final(c, base, sub_iter - 1, (float)tol, (float)rank_cap, s));
             HIP_TRY(c, hipMemcpyAsync(c->pinned, base + ScreenLayout::REC,
@@ -351,6 +355,7 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
                 done = i + 1;
                 if (code == 1) {
                     if (dist_trace) dist_trace[i] = rec[4 * i + 0];
+                    if (i > 0) min_margin = std::min(min_margin, (double)rec[4 * i + 0] / tol);
                     continue;
                 }
                 if (code == 2) {
@@ -359,6 +364,7 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
                     break;
                 }
                 double dist = nan;                        // bounds straddle tol: evaluate in full
+                undecided = true;
                 ONMF_TRY(exact_dist(c, r, b, buf[(i + 1) & 1], buf[i & 1], s, &dist, (double)rec[4 * i + 3], tol));
                 if (dist_trace) dist_trace[i] = (float)dist;
                 if (!keep_sweeping(dist, tol)) { stop = true; break; }
@@ -369,6 +375,8 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
             if (stop) break;
             start = next_start;
         }
+        // the next solve refreshes its probes if these left the bounds undecided or close to it
+        c->screen_refresh_due = undecided || min_margin < 1.5;
     } else {
         double dist = 1.0;      // src/onmf.py:251
         while (done < sub_iter && keep_sweeping(dist, tol)) {

@@ -51,6 +51,7 @@ struct onmf_ctx {
     int overlap_dict = 1;
     int screen_stop = 1;
     int screen_r = -1;              // r of the probes currently held in `screen`
+    bool screen_refresh_due = true; // the next screened solve runs a probe power step
     DevBuf ddelta;                  // dictionary pass: atom deltas (d x r), one-workgroup kernel
     int dict_kernel = 0;            // 0 = by shape, 1 = cooperative workgroups, 2 = one workgroup
     bool dict_coop_last = false;    // the last dictionary pass used the cooperative kernel (its timeout flag is live)
