@@ -71,6 +71,23 @@ def cpu_baseline(d, r, budget_cols):
                       "%d steps of %d columns (%d sweeps in the last), %.1f s" % (d, r, n, b, len(tr), el)}
 
 
+def measured_traffic(d, r, b):
+    """HBM bytes per sweep launch from the committed PMC passes (profiles/), when they are for this shape.
+
+    PMC counters cannot be collected from inside this process; the file holds the two rocprofv3
+    passes (FETCH_SIZE, WRITE_SIZE) of the same kernel at the same shape and how they were corrected.
+    """
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_sweep_hbm_traffic.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+    except (OSError, ValueError):
+        return None
+    if rec.get("shape") != {"d": d, "r": r, "b": b}:
+        return None
+    return rec.get("hbm_bytes_per_launch")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -170,7 +187,7 @@ def main():
             ach = per_launch / (avg_ms * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "kernel": "code sweep (one launch = one sweep over the batch)",
                                "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                               "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": measured_traffic(d, r, b),
                                "avg_launch_ms": avg_ms, "launches": sweep_launches}
         if not args.no_cpu_baseline:
             cols = args.cpu_cols or min(b, 4096)
