@@ -150,9 +150,8 @@ __global__ void dict_pad_kernel(int r, int lda, const float* __restrict__ A, flo
 
 template <int RPT>
 __global__ __launch_bounds__(256) void dict_panel_kernel(int d, int r, int lda,
-                                                         const float* __restrict__ Qt0,
+                                                         const float* __restrict__ Qt0,   // A^T W^T - B
                                                          const float* __restrict__ Ap,
-                                                         const float* __restrict__ B,
                                                          const float* __restrict__ Wt,
                                                          float* __restrict__ WtOut, float* Dt) {
     constexpr int PW = 16;
@@ -167,7 +166,6 @@ __global__ __launch_bounds__(256) void dict_panel_kernel(int d, int r, int lda,
     // 0 and drop their stores (range check), so they need no masks: their u is max(0 - 0, 0) = 0.
     const unsigned nbytes = (unsigned)r * (unsigned)d * 4u;
     const auto rs_q = __builtin_amdgcn_make_buffer_rsrc((void*)Qt0, 0, nbytes, 0x00020000);
-    const auto rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, nbytes, 0x00020000);
     const auto rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)Wt, 0, nbytes, 0x00020000);
     const auto rs_o = __builtin_amdgcn_make_buffer_rsrc((void*)WtOut, 0, nbytes, 0x00020000);
     const auto rs_d = __builtin_amdgcn_make_buffer_rsrc((void*)Dt, 0, nbytes, 0x00020000);
@@ -189,14 +187,13 @@ __global__ __launch_bounds__(256) void dict_panel_kernel(int d, int r, int lda,
 
     for (int j0 = 0; j0 < r; j0 += PW) {
         float q[RPT][PW], w[RPT][PW];
-        // this panel's entries of Q0 - B and of W
+        // this panel's entries of Q0 - B (formed by the product's epilogue) and of W
 #pragma unroll
         for (int p = 0; p < RPT; ++p) {
 #pragma unroll
             for (int n = 0; n < PW; ++n) {
                 const int so = (j0 + n) * rowbytes;
-                q[p][n] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_q, voff[p], so, 0)) -
-                          __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_b, voff[p], so, 0));
+                q[p][n] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_q, voff[p], so, 0));
                 w[p][n] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_w, voff[p], so, 0));
             }
             __builtin_amdgcn_sched_barrier(0);           // one row set at a time: 48 loads in flight, not 192
@@ -316,8 +313,8 @@ int launch_dict_pass(onmf_ctx* c, int d, int r, const float* Win, const float* A
         // Qt0[j][i] = sum_k A[k][j] * W[i][k]
         ONMF_TRY(onmf_reserve(c, c->qt, (size_t)r * d * sizeof(float), "dictionary Qt"));
         float* Qt = (float*)c->qt.p;
-        ONMF_TRY(launch_gemm(c, /*a_km=*/true, /*b_kn=*/false, r, d, r, A, r, Win, r, 1.f, 0.f, nullptr,
-                             Qt, d, s, &c->slab_side));
+        ONMF_TRY(launch_gemm(c, /*a_km=*/true, /*b_kn=*/false, r, d, r, A, r, Win, r, 1.f, -1.f, B,
+                             Qt, d, s, &c->slab_side));               // Qt = A^T W^T - B
         const int lda = (r + 15) / 16 * 16;
         ONMF_TRY(onmf_reserve(c, c->ddelta, (3 * (size_t)d * r + (size_t)r * lda + 16) * sizeof(float),
                               "dictionary deltas"));
@@ -332,7 +329,7 @@ int launch_dict_pass(onmf_ctx* c, int d, int r, const float* Win, const float* A
         const int rpt = (d + 255) / 256;
         const int nt = rpt > 1 ? 256 : (d + 63) / 64 * 64;
 #define PANEL_CASE(RPTV)                                                                              \
-    hipLaunchKernelGGL((dict_panel_kernel<RPTV>), dim3(1), dim3(nt), 0, s, d, r, lda, Qt, Ap, B, Wt, WtOut, Dt)
+    hipLaunchKernelGGL((dict_panel_kernel<RPTV>), dim3(1), dim3(nt), 0, s, d, r, lda, Qt, Ap, Wt, WtOut, Dt)
         if (rpt <= 1) PANEL_CASE(1);
         else if (rpt <= 2) PANEL_CASE(2);
         else PANEL_CASE(4);
