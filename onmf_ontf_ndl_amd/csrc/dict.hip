@@ -156,6 +156,7 @@ __global__ __launch_bounds__(256) void dict_panel_kernel(int d, int r, int lda,
                                                          float* __restrict__ WtOut, float* Dt) {
     constexpr int PW = 16;
     __shared__ __attribute__((aligned(16))) float part[2][16];   // one slot per wave; unused slots stay 0
+    __shared__ __attribute__((aligned(16))) float ablk[256];     // the panel's 16 x 16 block of Ap
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, c16 = lane & 15, g4 = lane >> 4;
     const bool lane0 = lane == 0;
@@ -261,11 +262,24 @@ __global__ __launch_bounds__(256) void dict_panel_kernel(int d, int r, int lda,
         // per SIMD) run it: every wave repeats the chain, and waves that share a SIMD would take
         // turns at every one of its steps.  The row of A for the next atom is fetched right after
         // the barrier, a whole atom ahead of its use.
-        Row16 acur = *reinterpret_cast<const Row16*>(Ap + (size_t)min(j0, r - 1) * lda + j0);
+        // The panel's 16 x 16 block of Ap goes through LDS: every lane then reads the same address
+        // (a broadcast), in order with the other LDS traffic of the chain, where a scalar load
+        // would make each wait for LDS also a wait for the scalar cache.
+        __syncthreads();                                      // previous panel's readers are done
+        for (int e = tid; e < 256; e += (int)blockDim.x)       // rows past r read as 0 (range check)
+            ablk[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                rs_a, ((e >> 4) * lda + (e & 15)) * 4, (j0 * lda + j0) * 4, 0));
+        __syncthreads();
+        float acur[PW];
+#pragma unroll
+        for (int m = 0; m < PW; m += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(ablk + m);
+            acur[m] = v.x; acur[m + 1] = v.y; acur[m + 2] = v.z; acur[m + 3] = v.w;
+        }
 #pragma unroll
         for (int n = 0; n < PW; ++n) {
             const int j = j0 + n;
-            const float ninv = acur.v[n];                     // diagonal slot: -1 / (A[j][j] + 1)
+            const float ninv = acur[n];                       // diagonal slot: -1 / (A[j][j] + 1)
             float u[RPT];
             float ss = 0.f;
 #pragma unroll
@@ -277,11 +291,20 @@ __global__ __launch_bounds__(256) void dict_panel_kernel(int d, int r, int lda,
             if (lane0) part[n & 1][wave] = ws;
             __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): the LDS write has landed
             __builtin_amdgcn_s_barrier();
-            Row16 anext = acur;
-            if (n + 1 < PW) anext = *reinterpret_cast<const Row16*>(Ap + (size_t)min(j + 1, r - 1) * lda + j0);
             // the 16 slots, one per lane of a row, summed by the same tree in every wave
+            const float psum = part[n & 1][c16];
+            float anext[PW];
+#pragma unroll
+            for (int m = 0; m < PW; ++m) anext[m] = acur[m];
+            if (n + 1 < PW) {
+#pragma unroll
+                for (int m = 0; m < PW; m += 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(ablk + (n + 1) * 16 + m);
+                    anext[m] = v.x; anext[m + 1] = v.y; anext[m + 2] = v.z; anext[m + 3] = v.w;
+                }
+            }
             const float total = __builtin_bit_cast(
-                float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, row_total(part[n & 1][c16])), 15));
+                float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, row_total(psum)), 15));
             const float scale = total > 1.0f ? __builtin_amdgcn_rsqf(total) : 1.0f;
 #pragma unroll
             for (int p = 0; p < RPT; ++p) {
@@ -291,12 +314,14 @@ __global__ __launch_bounds__(256) void dict_panel_kernel(int d, int r, int lda,
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dv), rs_d, voff[p], j * rowbytes, 0);
 #pragma unroll
                 for (int m = 0; m < PW; ++m)             // (constant bounds: unrolls before n is known)
-                    if (m > n) q[p][m] = fmaf(acur.v[m], dv, q[p][m]);
+                    if (m > n) q[p][m] = fmaf(acur[m], dv, q[p][m]);
             }
-            acur = anext;
+#pragma unroll
+            for (int m = 0; m < PW; ++m) acur[m] = anext[m];
         }
     }
 }
+
 
 __global__ void zero_u64_kernel(u64* p, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
