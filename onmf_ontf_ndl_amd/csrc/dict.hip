@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void dict_panel_kernel(int d, int r, int lda,
         // A operand: lane (g, c) = Ap[k0 + g][j0 + c]; B operand: Dt[k0 + g][tile row c].
         // D leaves atoms 4g..4g+3 of row c in lane (g, c); a 4x4 transpose between the tile index
         // and the lane row then hands lane 16g + c all 16 atoms of ITS row (tile g, row c).
-        // Operands are fetched two groups of four atoms ahead (one wave per SIMD: nothing else
+        // Operands are fetched four groups of four atoms ahead (one wave per SIMD: nothing else
         // covers the L2 latency).
         {
             f32x4 D[RPT][4];
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void dict_panel_kernel(int d, int r, int lda,
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) D[p][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
             const int ngroups = j0 >> 2;                      // a multiple of 4
-            float a0 = 0.f, a1 = 0.f, b0[RPT][4], b1[RPT][4];
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, b0[RPT][4], b1[RPT][4], b2[RPT][4], b3[RPT][4];
             auto fetch = [&](int kg, float& a, float (&bv)[RPT][4]) {
                 a = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_a, voffA, (4 * kg * lda + j0) * 4, 0));
 #pragma unroll
@@ -231,15 +231,21 @@ __global__ __launch_bounds__(256) void dict_panel_kernel(int d, int r, int lda,
                     for (int mt = 0; mt < 4; ++mt)
                         D[p][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[p][mt], D[p][mt], 0, 0, 0);
             };
-            if (ngroups > 0) {
+            if (ngroups > 0) {                                // ngroups is a multiple of 4
                 fetch(0, a0, b0);
                 fetch(1, a1, b1);
+                fetch(2, a2, b2);
+                fetch(3, a3, b3);
             }
-            for (int kg = 0; kg < ngroups; kg += 2) {
+            for (int kg = 0; kg < ngroups; kg += 4) {         // past the end: fetches the last group again
                 apply(a0, b0);
-                fetch(min(kg + 2, ngroups - 1), a0, b0);      // past the end: fetches the last group again
+                fetch(min(kg + 4, ngroups - 1), a0, b0);
                 apply(a1, b1);
-                fetch(min(kg + 3, ngroups - 1), a1, b1);
+                fetch(min(kg + 5, ngroups - 1), a1, b1);
+                apply(a2, b2);
+                fetch(min(kg + 6, ngroups - 1), a2, b2);
+                apply(a3, b3);
+                fetch(min(kg + 7, ngroups - 1), a3, b3);
             }
 #pragma unroll
             for (int p = 0; p < RPT; ++p) {
