@@ -179,7 +179,7 @@ int onmf_destroy(onmf_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     DevBuf* bufs[] = {&c->slab, &c->cm, &c->gram, &c->hbuf[0], &c->hbuf[1], &c->stats, &c->small,
-                      &c->qt, &c->sync, &c->idx, &c->dbuf, &c->slab_side, &c->screen, &c->ddelta};
+                      &c->qt, &c->sync, &c->idx, &c->dbuf, &c->slab_side, &c->screen, &c->ddelta, &c->slab_prep};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (c->pinned) (void)hipHostFree(c->pinned);
@@ -187,6 +187,9 @@ int onmf_destroy(onmf_ctx* c) {
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->side) (void)hipStreamDestroy(c->side);
+    if (c->prep) (void)hipStreamDestroy(c->prep);
+    if (c->ev_prep_fork) (void)hipEventDestroy(c->ev_prep_fork);
+    if (c->ev_prep_join) (void)hipEventDestroy(c->ev_prep_join);
     delete c;
     return ONMF_OK;
 }
@@ -293,20 +296,47 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
                                              (size_t)ScreenLayout::TOTAL * sizeof(float))));
     float* Gm = (float*)c->gram.p;
     float* Cm = (float*)c->cm.p;
-    // Gm = W^T W,  Cm = W^T X   (src/onmf.py:242-243)
-    ONMF_TRY(launch_gemm(c, true, true, r, r, d, W, r, W, r, 1.f, 0.f, nullptr, Gm, r, s));
-    ONMF_TRY(launch_gemm(c, true, true, r, b, d, W, r, X, ldx, 1.f, 0.f, nullptr, Cm, b, s));
+    // Gm = W^T W,  Cm = W^T X   (src/onmf.py:242-243).  Gm, the initial code and the screen state are
+    // small and independent of the big product: they go to a stream of their own (default priority)
+    // and run beside it instead of in front of it.
+    float* buf[2];
     // Sweep i reads buf[i & 1] and writes buf[(i + 1) & 1].  The caller's H is one of the two
     // buffers, placed so that a solve that runs all sub_iter sweeps ends in it (no final copy).
-    float* buf[2];
     buf[sub_iter & 1] = H;
     buf[(sub_iter + 1) & 1] = (float*)c->hbuf[0].p;
-    if (H0) {
-        if (H0 != buf[0])
-            HIP_TRY(c, hipMemcpyAsync(buf[0], H0, rb * sizeof(float), hipMemcpyDeviceToDevice, s));
-    } else {
-        ONMF_TRY(launch_fill_uniform(buf[0], rb, seed, s));
+    hipStream_t ps = s;
+    if (c->overlap_dict) {
+        if (!c->prep) {
+            HIP_TRY(c, hipStreamCreateWithFlags(&c->prep, hipStreamNonBlocking));
+            HIP_TRY(c, hipEventCreateWithFlags(&c->ev_prep_fork, hipEventDisableTiming));
+            HIP_TRY(c, hipEventCreateWithFlags(&c->ev_prep_join, hipEventDisableTiming));
+        }
+        ps = c->prep;
+        HIP_TRY(c, hipEventRecord(c->ev_prep_fork, s));
+        HIP_TRY(c, hipStreamWaitEvent(ps, c->ev_prep_fork, 0));
     }
+    int prep_rc = launch_gemm(c, true, true, r, r, d, W, r, W, r, 1.f, 0.f, nullptr, Gm, r, ps,
+                              ps == s ? nullptr : &c->slab_prep);
+    if (prep_rc == ONMF_OK) {
+        if (H0) {
+            if (H0 != buf[0] &&
+                hipMemcpyAsync(buf[0], H0, rb * sizeof(float), hipMemcpyDeviceToDevice, ps) != hipSuccess)
+                prep_rc = onmf_fail(c, ONMF_ERR_HIP, "sparse_code: copy of H0 failed");
+        } else {
+            prep_rc = launch_fill_uniform(buf[0], rb, seed, ps);
+        }
+    }
+    const int cm_rc = launch_gemm(c, true, true, r, b, d, W, r, X, ldx, 1.f, 0.f, nullptr, Cm, b, s);
+    if (ps != s) {                       // always rejoin, also on an error path
+        hipError_t e1 = hipEventRecord(c->ev_prep_join, ps);
+        hipError_t e2 = hipStreamWaitEvent(s, c->ev_prep_join, 0);
+        if (prep_rc == ONMF_OK && cm_rc == ONMF_OK) {
+            HIP_TRY(c, e1);
+            HIP_TRY(c, e2);
+        }
+    }
+    ONMF_TRY(prep_rc);
+    ONMF_TRY(cm_rc);
     const double tol = (double)stopping_diff;
     const double rank_cap = (double)std::min(r, b);
     const int exact_cd = (coder_mode == ONMF_CODER_EXACT_CD);

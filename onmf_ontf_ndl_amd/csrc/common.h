@@ -48,6 +48,9 @@ struct onmf_ctx {
     DevBuf slab_side;               // split-K slabs of products issued on the side stream
     hipStream_t side = nullptr;     // dictionary pass runs here, beside the code solve
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t prep = nullptr;     // the solve's small preparations run here, beside the W^T X product
+    hipEvent_t ev_prep_fork = nullptr, ev_prep_join = nullptr;
+    DevBuf slab_prep;               // split-K slabs of products issued on the preparation stream
     int overlap_dict = 1;
     int screen_stop = 1;
     int screen_r = -1;              // r of the probes currently held in `screen`
