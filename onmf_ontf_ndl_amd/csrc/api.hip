@@ -7,6 +7,8 @@
 
 #include "common.h"
 
+#include <functional>
+
 // ---------------------------------------------------------------------------------------------
 // context helpers
 // ---------------------------------------------------------------------------------------------
@@ -186,6 +188,7 @@ int onmf_destroy(onmf_ctx* c) {
     for (hipEvent_t ev : c->ev) (void)hipEventDestroy(ev);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->ev_rec) (void)hipEventDestroy(c->ev_rec);
     if (c->side) (void)hipStreamDestroy(c->side);
     if (c->prep) (void)hipStreamDestroy(c->prep);
     if (c->ev_prep_fork) (void)hipEventDestroy(c->ev_prep_fork);
@@ -282,7 +285,13 @@ static int exact_dist(onmf_ctx* c, int r, int b, const float* Hnew, const float*
 static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, int ldx,
                             const float* W, const float* H0, uint64_t seed, float alpha,
                             int sub_iter, float stopping_diff, int coder_mode, float* H,
-                            int* sweeps_done, float* dist_trace, hipStream_t s) {
+                            int* sweeps_done, float* dist_trace, hipStream_t s,
+                            const std::function<int()>* after = nullptr, bool* after_valid = nullptr) {
+    // `after`: work that consumes H (the step's aggregate products).  When the solve is enqueued as a
+    // whole, it is enqueued too BEFORE the host waits for the verdicts, so the GPU does not idle
+    // through that round trip; *after_valid tells the caller whether that run stands (it does not if
+    // the host had to finish the solve: then the caller runs the work again).
+    if (after_valid) *after_valid = false;
     if (d <= 0 || r <= 0 || b <= 0 || !X || !W || !H || ldx < b || sub_iter < 0)
         return onmf_fail(c, ONMF_ERR_ARG, "sparse_code: bad arguments (d=%d r=%d b=%d ldx=%d)", d, r, b, ldx);
     HIP_TRY(c, hipSetDevice(c->device));
@@ -354,7 +363,7 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
         const bool refresh_probes = c->screen_refresh_due || c->screen_r != r;
         ONMF_TRY(launch_screen_init(c, base, r, s));
         double min_margin = 1e300;       // smallest (lower bound / tol) among the "continue" verdicts
-        bool undecided = false;
+        bool undecided = false, posted = false;
         int start = 0;
         while (start < sub_iter) {
             for (int i = start; i < sub_iter; ++i) {
@@ -374,7 +383,17 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
             ONMF_TRY(launch_screen_final(c, base, sub_iter - 1, (float)tol, (float)rank_cap, s));
             HIP_TRY(c, hipMemcpyAsync(c->pinned, base + ScreenLayout::REC,
                                       (size_t)4 * SCREEN_MAX_SWEEPS * sizeof(float), hipMemcpyDeviceToHost, s));
-            HIP_TRY(c, hipStreamSynchronize(s));
+            if (after && start == 0 && (rb & 3) == 0) {
+                // the host waits for the records only; the follow-up work is already behind them
+                if (!c->ev_rec) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_rec, hipEventDisableTiming));
+                HIP_TRY(c, hipEventRecord(c->ev_rec, s));
+                ONMF_TRY(launch_screen_finalize(c, base, sub_iter, buf[(sub_iter + 1) & 1], H, rb, s));
+                ONMF_TRY((*after)());
+                posted = true;
+                HIP_TRY(c, hipEventSynchronize(c->ev_rec));
+            } else {
+                HIP_TRY(c, hipStreamSynchronize(s));
+            }
             const float* rec = (const float*)c->pinned;
             int next_start = sub_iter;
             bool stop = false;
@@ -407,6 +426,13 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
         }
         // the next solve refreshes its probes if these left the bounds undecided or close to it
         c->screen_refresh_due = undecided || min_margin < 1.5;
+        if (posted && !undecided) {      // the device put the result in H and the follow-up work stands
+            if (after_valid) *after_valid = true;
+            if (sweeps_done) *sweeps_done = done;
+            if (dist_trace)
+                for (int i = done; i < sub_iter; ++i) dist_trace[i] = std::numeric_limits<float>::quiet_NaN();
+            return ONMF_OK;
+        }
     } else {
         double dist = 1.0;      // src/onmf.py:251
         while (done < sub_iter && keep_sweeping(dist, tol)) {
@@ -563,11 +589,14 @@ int onmf_step(onmf_ctx* c, int d, int r, int b, const float* X, int ldx, const f
         int rc = launch_dict_pass(c, d, r, W_in, A_in, B_in, W_out, c->side);
         hipError_t e1 = hipEventRecord(c->ev_join, c->side);
         int rc2 = ONMF_OK;
+        bool agg_done = false;
+        const std::function<int()> agg = [&]() {
+            return aggregate_impl(c, d, r, b, X, ldx, H, w, A_in, B_in, C_in, A_out, B_out, C_out, s);
+        };
         if (rc == ONMF_OK)
             rc2 = sparse_code_impl(c, d, r, b, X, ldx, W_in, H0, seed, alpha, sub_iter, stopping_diff,
-                                   ONMF_CODER_DAMPED, H, sweeps_done, dist_trace, s);
-        if (rc == ONMF_OK && rc2 == ONMF_OK)
-            rc2 = aggregate_impl(c, d, r, b, X, ldx, H, w, A_in, B_in, C_in, A_out, B_out, C_out, s);
+                                   ONMF_CODER_DAMPED, H, sweeps_done, dist_trace, s, &agg, &agg_done);
+        if (rc == ONMF_OK && rc2 == ONMF_OK && !agg_done) rc2 = agg();
         // always rejoin, also on an error path, so the side stream never outlives the call's buffers
         hipError_t e2 = hipStreamWaitEvent(s, c->ev_join, 0);
         if (rc != ONMF_OK) return rc;

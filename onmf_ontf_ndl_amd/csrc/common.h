@@ -47,7 +47,7 @@ struct onmf_ctx {
     DevBuf screen;                  // stopping-test screen state (ScreenLayout)
     DevBuf slab_side;               // split-K slabs of products issued on the side stream
     hipStream_t side = nullptr;     // dictionary pass runs here, beside the code solve
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_rec = nullptr;
     hipStream_t prep = nullptr;     // the solve's small preparations run here, beside the W^T X product
     hipEvent_t ev_prep_fork = nullptr, ev_prep_join = nullptr;
     DevBuf slab_prep;               // split-K slabs of products issued on the preparation stream
@@ -166,6 +166,9 @@ int launch_screen_init(onmf_ctx* c, float* base, int r, hipStream_t s);
 // verdict of sweep k_last (the last one enqueued), which no later sweep evaluates
 int launch_screen_final(onmf_ctx* c, float* base, int k_last, float tol, float rank_cap, hipStream_t s);
 int launch_screen_clear_flag(onmf_ctx* c, float* base, hipStream_t s);
+// device-side: copy src to dst if the verdict records say the solve ended in src
+int launch_screen_finalize(onmf_ctx* c, const float* base, int sub_iter, const float* src, float* dst,
+                           size_t n, hipStream_t s);
 // one power step of the probe subspace on a sample of columns, then the probe update
 int launch_screen_refresh(onmf_ctx* c, float* base, int r, int b, const float* Hnew, const float* Hold,
                           hipStream_t s);

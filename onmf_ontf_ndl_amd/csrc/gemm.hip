@@ -321,7 +321,8 @@ int launch_gemm(onmf_ctx* c, bool a_km, bool b_kn, int M, int N, int K, const fl
     const int ktiles = (K + BK - 1) / BK;
     int splits = 1;
     if (tiles < 256 && ktiles >= 4) {
-        splits = (512 + tiles - 1) / tiles;
+        // few tiles: one workgroup per CU is enough, and half as many slabs for the reduction to read
+        splits = ((tiles <= 4 ? 256 : 512) + tiles - 1) / tiles;
         const int max_by_k = ktiles / 2;          // at least 2 k-tiles of work per slab
         if (splits > max_by_k) splits = max_by_k;
         if (splits < 1) splits = 1;

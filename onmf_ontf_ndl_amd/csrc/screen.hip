@@ -165,6 +165,29 @@ __global__ __launch_bounds__(64) void screen_final_kernel(float* base, int k, fl
     }
 }
 
+// After the last sweep of an enqueue: put the solve's result into the caller's buffer if it ended in
+// the library's one.  The verdict records say where it ended: sweeps 0..done-1 ran, the result is
+// in buffer (done & 1), the caller's buffer is number (sub_iter & 1).  An inconclusive record means
+// the host will finish the solve: nothing to do here.
+__global__ __launch_bounds__(256) void screen_finalize_kernel(const float* base, int sub_iter,
+                                                              const float4* __restrict__ src,
+                                                              float4* __restrict__ dst, size_t n4) {
+    __shared__ int copy_s;
+    if (threadIdx.x == 0) {
+        int done = sub_iter, undecided = 0;
+        for (int i = 0; i < sub_iter; ++i) {
+            const int code = (int)base[ScreenLayout::REC + 4 * i + 2];
+            if (code == 2) { done = i + 1; break; }
+            if (code != 1) { undecided = 1; break; }
+        }
+        copy_s = (!undecided && ((done ^ sub_iter) & 1)) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!copy_s) return;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
+        dst[i] = src[i];
+}
+
 // Probe update after a power step: one workgroup of 256 threads; thread k owns row k of the
 // r_pad <= 256 rows of Z.
 __global__ __launch_bounds__(256) void screen_probe_update_kernel(float* base, int r) {
@@ -289,6 +312,16 @@ int launch_screen_init(onmf_ctx* c, float* base, int r, hipStream_t s) {
 
 int launch_screen_final(onmf_ctx* c, float* base, int k_last, float tol, float rank_cap, hipStream_t s) {
     hipLaunchKernelGGL(screen_final_kernel, dim3(1), dim3(64), 0, s, base, k_last, tol, rank_cap);
+    HIP_TRY(c, hipGetLastError());
+    return ONMF_OK;
+}
+
+int launch_screen_finalize(onmf_ctx* c, const float* base, int sub_iter, const float* src, float* dst,
+                           size_t n, hipStream_t s) {
+    if ((n & 3) || (((uintptr_t)src | (uintptr_t)dst) & 15))
+        return onmf_fail(c, ONMF_ERR_ARG, "screen finalize: buffers must be 16-byte aligned multiples of 4 floats");
+    hipLaunchKernelGGL(screen_finalize_kernel, dim3(1024), dim3(256), 0, s, base, sub_iter,
+                       (const float4*)src, (float4*)dst, n / 4);
     HIP_TRY(c, hipGetLastError());
     return ONMF_OK;
 }
