@@ -138,6 +138,9 @@ double onmf_host_lambda_max(const float* S_host, int n);
  *                          bounds straddle stopping_diff.  0: one host decision per sweep.
  *   ONMF_OPT_DICT_KERNEL   0 = pick by shape, 1 = cooperating one-wave workgroups (any d <= 16384),
  *                          2 = one workgroup (d <= 4096).
+ *   ONMF_OPT_PERSISTENT_SWEEPS != 0 (default): with the screened stopping test, run all sweeps of
+ *                          a solve in one launch when its grid (one workgroup per 256 columns)
+ *                          fits the chip's CUs; 0: one launch per sweep.
  */
 #define ONMF_OPT_PROFILE 1
 #define ONMF_OPT_EXACT_STOP 2
@@ -145,6 +148,7 @@ double onmf_host_lambda_max(const float* S_host, int n);
 #define ONMF_OPT_OVERLAP_DICT 4
 #define ONMF_OPT_SCREEN_STOP 5
 #define ONMF_OPT_DICT_KERNEL 6
+#define ONMF_OPT_PERSISTENT_SWEEPS 7
 int onmf_set_option(onmf_ctx* ctx, int key, int value);
 /* Summed device time (ms) and number of sweep-kernel launches since the previous call. */
 int onmf_get_profile(onmf_ctx* ctx, double* sweep_ms, int* sweep_launches);

@@ -21,6 +21,7 @@ OPT_SWEEP_KERNEL = 3
 OPT_OVERLAP_DICT = 4
 OPT_SCREEN_STOP = 5
 OPT_DICT_KERNEL = 6
+OPT_PERSISTENT_SWEEPS = 7
 
 _f = C.c_void_p          # device float*
 _ctx = C.c_void_p

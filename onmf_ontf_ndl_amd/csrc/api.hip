@@ -208,6 +208,7 @@ int onmf_set_option(onmf_ctx* c, int key, int value) {
         case ONMF_OPT_OVERLAP_DICT: c->overlap_dict = value; return ONMF_OK;
         case ONMF_OPT_SCREEN_STOP: c->screen_stop = value; return ONMF_OK;
         case ONMF_OPT_DICT_KERNEL: c->dict_kernel = value; return ONMF_OK;
+        case ONMF_OPT_PERSISTENT_SWEEPS: c->persistent_sweeps = value; return ONMF_OK;
         default: return onmf_fail(c, ONMF_ERR_ARG, "onmf_set_option: unknown key %d", key);
     }
 }
@@ -299,6 +300,7 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
     ONMF_TRY(onmf_reserve(c, c->gram, (size_t)r * r * sizeof(float), "Gm"));
     ONMF_TRY(onmf_reserve(c, c->cm, rb * sizeof(float), "Cm"));
     ONMF_TRY(onmf_reserve(c, c->hbuf[0], rb * sizeof(float), "code buffer"));
+    ONMF_TRY(onmf_reserve(c, c->hbuf[1], rb * sizeof(float), "code buffer"));
     const int max_groups = (b + 15) / 16 + 64;
     ONMF_TRY(onmf_reserve(c, c->stats, (size_t)max_groups * 2 * sizeof(double), "sweep statistics"));
     ONMF_TRY(onmf_reserve_pinned(c, std::max((size_t)max_groups * 2 * sizeof(double),
@@ -308,11 +310,13 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
     // Gm = W^T W,  Cm = W^T X   (src/onmf.py:242-243).  Gm, the initial code and the screen state are
     // small and independent of the big product: they go to a stream of their own (default priority)
     // and run beside it instead of in front of it.
-    float* buf[2];
-    // Sweep i reads buf[i & 1] and writes buf[(i + 1) & 1].  The caller's H is one of the two
-    // buffers, placed so that a solve that runs all sub_iter sweeps ends in it (no final copy).
-    buf[sub_iter & 1] = H;
-    buf[(sub_iter + 1) & 1] = (float*)c->hbuf[0].p;
+    // Sweep i reads buf[i % 3] and writes buf[(i + 1) % 3]: three buffers, so that a sweep that ran
+    // ahead of the stopping test's verdict has overwritten neither side of the tested pair.  The
+    // caller's H is one of them, placed so that a solve that runs all sub_iter sweeps ends in it.
+    float* buf[3];
+    buf[sub_iter % 3] = H;
+    buf[(sub_iter + 1) % 3] = (float*)c->hbuf[0].p;
+    buf[(sub_iter + 2) % 3] = (float*)c->hbuf[1].p;
     hipStream_t ps = s;
     if (c->overlap_dict) {
         if (!c->prep) {
@@ -356,38 +360,48 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
                           c->sweep_kernel != 1 && sweep_tile_covers(r, b) &&
                           sub_iter <= SCREEN_MAX_SWEEPS && keep_sweeping(1.0, tol);
     if (screened) {
-        // All sweeps and their verdict kernels are enqueued without host round trips; sweeps after a
-        // "stop"/"inconclusive" verdict return at once and leave both code buffers untouched.
+        // All sweeps are enqueued without host round trips - as ONE launch that runs them all when
+        // the grid is resident as a whole (one workgroup per CU), else one launch per sweep; they
+        // evaluate the stopping test themselves (two sweeps back) and end when it says so.
         ONMF_TRY(onmf_reserve(c, c->screen, (size_t)ScreenLayout::TOTAL * sizeof(float), "stop-test screen"));
         float* base = (float*)c->screen.p;
         const bool refresh_probes = c->screen_refresh_due || c->screen_r != r;
         ONMF_TRY(launch_screen_init(c, base, r, s));
         double min_margin = 1e300;       // smallest (lower bound / tol) among the "continue" verdicts
         bool undecided = false, posted = false;
+        if (c->cu_count == 0) {
+            int cus = 0;
+            HIP_TRY(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+            c->cu_count = cus;
+        }
+        const bool persistent = c->persistent_sweeps && sweep_tile_workgroups(b) <= c->cu_count;
         int start = 0;
         while (start < sub_iter) {
-            for (int i = start; i < sub_iter; ++i) {
-                const float damp = (float)std::sqrt((double)i + 10.0);
+            const ScreenDev sc = {base, start, (float)tol, (float)rank_cap, 200000000LL /* 2 s */};
+            int i = start;
+            while (i < sub_iter) {
+                // the first sweep of the solve stands alone when a probe power step follows it
+                int count = persistent ? sub_iter - i : 1;
+                if (i == 0 && refresh_probes) count = 1;
                 int groups = 0;
-                // sweep i evaluates sweep i-1's test in its prologue (not the first one launched
-                // here: there is none before sweep 0, and the host settled the one before a relaunch)
-                const ScreenDev sc = {base, i, i == start ? 1 : 0, (float)tol, (float)rank_cap};
                 ONMF_TRY(profile_mark(c, s));
-                ONMF_TRY(launch_sweep(c, r, b, Gm, Cm, buf[i & 1], buf[(i + 1) & 1], alpha, damp, 0,
-                                      (double*)c->stats.p, &groups, s, &sc));
+                ONMF_TRY(launch_sweep(c, r, b, Gm, Cm, buf, alpha, 0, i, count, (double*)c->stats.p, &groups, s, &sc));
                 ONMF_TRY(profile_mark(c, s));
                 // a power step of the probe subspace on the first sweep's move, when the probes kept
                 // from the previous solve left little margin (or there are none yet)
                 if (i == 0 && refresh_probes) ONMF_TRY(launch_screen_refresh(c, base, r, b, buf[1], buf[0], s));
+                i += count;
             }
-            ONMF_TRY(launch_screen_final(c, base, sub_iter - 1, (float)tol, (float)rank_cap, s));
+            // a sweep evaluates the test of the one two sweeps back: the last two are still open
+            ONMF_TRY(launch_screen_final(c, base, std::max(start, sub_iter - 2), sub_iter - 1, (float)tol,
+                                         (float)rank_cap, s));
             HIP_TRY(c, hipMemcpyAsync(c->pinned, base + ScreenLayout::REC,
                                       (size_t)4 * SCREEN_MAX_SWEEPS * sizeof(float), hipMemcpyDeviceToHost, s));
             if (after && start == 0 && (rb & 3) == 0) {
                 // the host waits for the records only; the follow-up work is already behind them
                 if (!c->ev_rec) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_rec, hipEventDisableTiming));
                 HIP_TRY(c, hipEventRecord(c->ev_rec, s));
-                ONMF_TRY(launch_screen_finalize(c, base, sub_iter, buf[(sub_iter + 1) & 1], H, rb, s));
+                ONMF_TRY(launch_screen_finalize(c, base, sub_iter, buf, H, rb, s));
                 ONMF_TRY((*after)());
                 posted = true;
                 HIP_TRY(c, hipEventSynchronize(c->ev_rec));
@@ -399,8 +413,13 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
             bool stop = false;
             for (int i = start; i < sub_iter; ++i) {
                 const int code = (int)rec[4 * i + 2];     // 1 continue, 2 stop, 3 inconclusive
-                if (code == 0)
+                if (code == 0) {
+                    HIP_TRY(c, hipMemcpy(&done, base + ScreenLayout::FLAG, sizeof(int), hipMemcpyDeviceToHost));
+                    if (done == SCREEN_FLAG_TIMEOUT)
+                        return onmf_fail(c, ONMF_ERR_TIMEOUT,
+                                         "sparse_code: a sweep workgroup waited more than 2 s for the others");
                     return onmf_fail(c, ONMF_ERR_HIP, "sparse_code: sweep %d left no verdict", i);
+                }
                 done = i + 1;
                 if (code == 1) {
                     if (dist_trace) dist_trace[i] = rec[4 * i + 0];
@@ -414,10 +433,10 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
                 }
                 double dist = nan;                        // bounds straddle tol: evaluate in full
                 undecided = true;
-                ONMF_TRY(exact_dist(c, r, b, buf[(i + 1) & 1], buf[i & 1], s, &dist, (double)rec[4 * i + 3], tol));
+                ONMF_TRY(exact_dist(c, r, b, buf[(i + 1) % 3], buf[i % 3], s, &dist, (double)rec[4 * i + 3], tol));
                 if (dist_trace) dist_trace[i] = (float)dist;
                 if (!keep_sweeping(dist, tol)) { stop = true; break; }
-                if (i + 1 < sub_iter) ONMF_TRY(launch_screen_clear_flag(c, base, s));
+                if (i + 1 < sub_iter) ONMF_TRY(launch_screen_clear_flag(c, base, i + 1, s));
                 next_start = i + 1;
                 break;
             }
@@ -436,13 +455,11 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
     } else {
         double dist = 1.0;      // src/onmf.py:251
         while (done < sub_iter && keep_sweeping(dist, tol)) {
-            float* cur = buf[done & 1];
-            float* nxt = buf[(done + 1) & 1];
-            const float damp = (float)std::sqrt((double)done + 10.0);
+            float* cur = buf[done % 3];
+            float* nxt = buf[(done + 1) % 3];
             int groups = 0;
             ONMF_TRY(profile_mark(c, s));
-            ONMF_TRY(launch_sweep(c, r, b, Gm, Cm, cur, nxt, alpha, damp, exact_cd, (double*)c->stats.p,
-                                  &groups, s));
+            ONMF_TRY(launch_sweep(c, r, b, Gm, Cm, buf, alpha, exact_cd, done, 1, (double*)c->stats.p, &groups, s));
             ONMF_TRY(profile_mark(c, s));
             HIP_TRY(c, hipMemcpyAsync(c->pinned, c->stats.p, (size_t)groups * 2 * sizeof(double),
                                       hipMemcpyDeviceToHost, s));
@@ -491,8 +508,8 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
             ++done;
         }
     }
-    if (buf[done & 1] != H)
-        HIP_TRY(c, hipMemcpyAsync(H, buf[done & 1], rb * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (buf[done % 3] != H)
+        HIP_TRY(c, hipMemcpyAsync(H, buf[done % 3], rb * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (sweeps_done) *sweeps_done = done;
     if (dist_trace)
         for (int i = done; i < sub_iter; ++i) dist_trace[i] = std::numeric_limits<float>::quiet_NaN();

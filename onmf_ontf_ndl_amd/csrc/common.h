@@ -55,6 +55,8 @@ struct onmf_ctx {
     int screen_stop = 1;
     int screen_r = -1;              // r of the probes currently held in `screen`
     bool screen_refresh_due = true; // the next screened solve runs a probe power step
+    int persistent_sweeps = 1;      // all sweeps of a screened solve in one launch when the grid fits the chip
+    int cu_count = 0;
     DevBuf ddelta;                  // dictionary pass: atom deltas (d x r), one-workgroup kernel
     int dict_kernel = 0;            // 0 = by shape, 1 = cooperative workgroups, 2 = one workgroup
     bool dict_coop_last = false;    // the last dictionary pass used the cooperative kernel (its timeout flag is live)
@@ -87,27 +89,30 @@ int launch_gemm(onmf_ctx* c, bool a_km, bool b_kn, int M, int N, int K, const fl
                 const float* B, int ldb, float alpha, float beta, const float* Cin, float* C,
                 int ldc, hipStream_t s, DevBuf* slab = nullptr);
 
-// What a probing sweep needs of the stopping-test screen (screen.hip): the state block and its
-// own position in the solve.
+// What a probing sweep launch needs of the stopping-test screen (screen.hip).
 struct ScreenDev {
     float* base;         // ScreenLayout
-    int k;               // index of this sweep in the solve
-    int skip_verdict;    // != 0: do not evaluate the previous sweep's test (first sweep, or the host did)
+    int v_first;         // first sweep whose test is still open (earlier ones were settled before the launch)
     float tol;           // stopping_diff
     float rank_cap;      // min(r, b)
+    long long spin_limit;    // bound (100 MHz ticks) on waiting for the other workgroups' sums
 };
 
-// One Gauss-Seidel sweep over all rows: Hout = sweep(Hin).  stats (device, 2 doubles per
-// workgroup) receives sum((Hout-Hin)^2) and sum(Hin^2) partials; *n_groups = number of pairs.
-int launch_sweep_tile_ct1(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm, const float* Hin,
-                          float* Hout, float alpha, float damp, int exact_cd, double* stats,
+// Gauss-Seidel sweeps k_first .. k_first + k_count - 1 over all rows: sweep k reads hb[k % 3] (only
+// the first of a launch actually loads it) and writes hb[(k + 1) % 3].  stats (device, 2 doubles per
+// wave) receives sum((new - old)^2) and sum(old^2) partials of the LAST sweep run; *n_groups = number
+// of pairs.  With `screen` the sweeps also leave the stopping test's by-products and end themselves
+// when it says so (k_count > 1 needs `screen` and a grid that is resident as a whole).
+int launch_sweep_tile_ct1(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm, float* const* hb,
+                          float alpha, int exact_cd, int k_first, int k_count, double* stats,
                           int* n_groups, hipStream_t s, const ScreenDev* screen);
-int launch_sweep_tile_ct2(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm, const float* Hin,
-                          float* Hout, float alpha, float damp, int exact_cd, double* stats,
+int launch_sweep_tile_ct2(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm, float* const* hb,
+                          float alpha, int exact_cd, int k_first, int k_count, double* stats,
                           int* n_groups, hipStream_t s, const ScreenDev* screen);
-int launch_sweep(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm, const float* Hin,
-                 float* Hout, float alpha, float damp, int exact_cd, double* stats, int* n_groups,
+int launch_sweep(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm, float* const* hb,
+                 float alpha, int exact_cd, int k_first, int k_count, double* stats, int* n_groups,
                  hipStream_t s, const ScreenDev* screen = nullptr);
+int sweep_tile_workgroups(int b);
 bool sweep_tile_covers(int r, int b);
 
 // Stopping-test screen: state layout and kernels.
@@ -116,15 +121,14 @@ constexpr int SCREEN_REPL = 8;       // replicas of the sweep kernel's accumulat
 constexpr int SCREEN_ZREPL = 4;      // replicas of the power-step accumulator
 struct ScreenLayout {           // offsets in floats into ctx->screen
     static constexpr int UBLK = 0;                                 // 16 * 256: probe blocks
-    static constexpr int V = 4096;                                 // 2 x 256: sweep k reads V + (k & 1) * 256
-    static constexpr int ZACC = V + 512;                           // ZREPL x 256 x 16
-    // three accumulator sets; sweep k adds into set k % 3, reads set (k - 1) % 3, clears set (k + 1) % 3
+    static constexpr int ZACC = 4096;                              // ZREPL x 256 x 16
+    // one accumulator set per sweep of the solve (never reused: no clearing races)
     static constexpr int SETS = ZACC + SCREEN_ZREPL * 4096;
     static constexpr int SET_P2 = 0;                               // REPL x 16 probe energies
-    static constexpr int SET_Y = SCREEN_REPL * 16;                 // REPL x 256: H (H^T v)
-    static constexpr int SET_SUMS = SET_Y + SCREEN_REPL * 256;     // REPL x 2 doubles
+    static constexpr int SET_SUMS = SCREEN_REPL * 16;              // REPL x 2 doubles
     static constexpr int SETSZ = SET_SUMS + SCREEN_REPL * 4;
-    static constexpr int UBH = SETS + 3 * SETSZ;   // MAX_SWEEPS + 1: bound of sigma_max(H before sweep k)
+    static constexpr int CNT = SETS + SCREEN_MAX_SWEEPS * SETSZ;   // ints: workgroups done with sweep k
+    static constexpr int UBH = CNT + SCREEN_MAX_SWEEPS;            // MAX + 1: bound of sigma_max(H before sweep k)
     static constexpr int FLAG = UBH + SCREEN_MAX_SWEEPS + 1;       // int: 0 = keep sweeping
     static constexpr int AVEC = FLAG + 1;          // 16: last Ritz coefficient vector (warm start)
     static constexpr int REC = AVEC + 16;          // SCREEN_MAX_SWEEPS x 4 floats
@@ -132,12 +136,14 @@ struct ScreenLayout {           // offsets in floats into ctx->screen
 };
 static_assert(ScreenLayout::SETS % 2 == 0 && ScreenLayout::SETSZ % 2 == 0 && ScreenLayout::SET_SUMS % 2 == 0,
               "double alignment");
+constexpr int SCREEN_FLAG_TIMEOUT = 4;     // a workgroup gave up waiting for the others
 
 #if defined(__HIPCC__)
 // The three-way verdict of one sweep from its by-products (see screen.hip).  Deterministic: every
 // caller that feeds it the same numbers gets the same answer.  0 continue, 1 stop, 2 inconclusive.
 __device__ __forceinline__ int screen_verdict(float lb2, double dsum, double hsum, float ubp, float tol,
-                                              float rank_cap, float& lower_f, float& upper_f, float& ubh_f) {
+                                              float rank_cap, float& lower_f, float& upper_f, float& ubh_f,
+                                              float& ubnext_f) {
     const double fD = sqrt(dsum), fH = sqrt(hsum);
     double ubH = fH * (1.0 + 1e-5);                       // sigma_max <= Frobenius norm
     if (ubp > 0.f && (double)ubp < ubH) ubH = ubp;
@@ -158,16 +164,64 @@ __device__ __forceinline__ int screen_verdict(float lb2, double dsum, double hsu
     lower_f = (float)lower;
     upper_f = (float)fmin(upper, 3.0e38);
     ubh_f = (float)ubH;
+    // sigma_max(H_new) <= sigma_max(H_old) + sigma_max(H_new - H_old) <= ubH + ||H_new - H_old||_F
+    ubnext_f = (float)fmin((ubH + fD) * (1.0 + 1e-5), 3.0e38);
+    return verdict;
+}
+
+// The same for sweep j, from its accumulator set; called by all 64 lanes of one wave.  The set is
+// read with agent-scope atomic loads: within a launch the sums come from workgroups on other XCDs,
+// whose stores a plain load could miss in this XCD's L2.  `ub` carries the bound of
+// sigma_max(H before sweep j) in and the bound for sweep j + 1 out.  With `record` the caller is the
+// one workgroup that writes the verdict down.  Returns the verdict, wave-uniform.
+__device__ __forceinline__ int screen_eval_wave(float* base, int j, float& ub, float tol, float rank_cap,
+                                                bool record) {
+    const int lane = threadIdx.x & 63;
+    float* set = base + ScreenLayout::SETS + j * ScreenLayout::SETSZ;
+    float e = 0.f;
+    if (lane < 16)
+        for (int rp = 0; rp < SCREEN_REPL; ++rp)
+            e += __hip_atomic_load(set + ScreenLayout::SET_P2 + rp * 16 + lane, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) e = fmaxf(e, __shfl_xor(e, off));
+    int verdict = 0;
+    float ubn = ub;
+    if (lane == 0) {
+        double* sums = reinterpret_cast<double*>(set + ScreenLayout::SET_SUMS);
+        double dsum = 0.0, hsum = 0.0;
+        for (int rp = 0; rp < SCREEN_REPL; ++rp) {
+            dsum += __hip_atomic_load(sums + 2 * rp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            hsum += __hip_atomic_load(sums + 2 * rp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        float lower, upper, ubh;
+        verdict = screen_verdict(e, dsum, hsum, ub, tol, rank_cap, lower, upper, ubh, ubn);
+        if (record) {
+            float* rec = base + ScreenLayout::REC + 4 * j;
+            rec[0] = lower;
+            rec[1] = upper;
+            rec[2] = (float)(verdict + 1);                    // 0 = no verdict yet
+            rec[3] = ubh;
+            base[ScreenLayout::UBH + j + 1] = ubn;
+            if (verdict != 0)
+                __hip_atomic_store(reinterpret_cast<int*>(base) + ScreenLayout::FLAG, verdict, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    verdict = __builtin_amdgcn_readfirstlane(verdict);
+    ub = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ubn)));
     return verdict;
 }
 #endif
 
 int launch_screen_init(onmf_ctx* c, float* base, int r, hipStream_t s);
-// verdict of sweep k_last (the last one enqueued), which no later sweep evaluates
-int launch_screen_final(onmf_ctx* c, float* base, int k_last, float tol, float rank_cap, hipStream_t s);
-int launch_screen_clear_flag(onmf_ctx* c, float* base, hipStream_t s);
-// device-side: copy src to dst if the verdict records say the solve ended in src
-int launch_screen_finalize(onmf_ctx* c, const float* base, int sub_iter, const float* src, float* dst,
+// the verdicts that no sweep of the launch evaluated: sweeps k_from .. k_last, in order
+int launch_screen_final(onmf_ctx* c, float* base, int k_from, int k_last, float tol, float rank_cap,
+                        hipStream_t s);
+// reopen the loop after the host settled sweep k - 1: flag = 0, no bound known for sweep k
+int launch_screen_clear_flag(onmf_ctx* c, float* base, int k, hipStream_t s);
+// device-side: copy hb[done % 3] to dst, if that is another buffer, where done comes from the records
+int launch_screen_finalize(onmf_ctx* c, const float* base, int sub_iter, float* const* hb, float* dst,
                            size_t n, hipStream_t s);
 // one power step of the probe subspace on a sample of columns, then the probe update
 int launch_screen_refresh(onmf_ctx* c, float* base, int r, int b, const float* Hnew, const float* Hold,

@@ -31,11 +31,9 @@ __global__ __launch_bounds__(256) void screen_init_kernel(float* base, int r, in
     const float scale = 1.0f / sqrtf((float)r);              // |u_p|^2 <= r * scale^2 = 1
     // keep_probes: the probe vectors left by the previous solve (same r) are a better start than
     // pseudo-random ones - consecutive minibatches of a stream move the code along similar directions
-    const int first = keep_probes ? ScreenLayout::V : 0;
+    const int first = keep_probes ? ScreenLayout::ZACC : 0;
     for (int e = first + tid; e < ScreenLayout::TOTAL; e += 256) base[e] = 0.f;
     __syncthreads();
-    base[ScreenLayout::V + tid] = 1.0f;
-    base[ScreenLayout::V + 256 + tid] = 1.0f;
     if (tid <= SCREEN_MAX_SWEEPS) base[ScreenLayout::UBH + tid] = -1.0f;     // no bound known
     if (tid < r && !keep_probes) {
         const int K = tid >> 4, j = tid & 15;
@@ -45,10 +43,12 @@ __global__ __launch_bounds__(256) void screen_init_kernel(float* base, int r, in
     if (tid == 0) base[ScreenLayout::AVEC] = 1.0f;
 }
 
-__global__ void screen_clear_flag_kernel(float* base) {
-    if (threadIdx.x == 0) reinterpret_cast<int*>(base)[ScreenLayout::FLAG] = 0;
+__global__ void screen_clear_flag_kernel(float* base, int k) {
+    if (threadIdx.x == 0) {
+        reinterpret_cast<int*>(base)[ScreenLayout::FLAG] = 0;
+        base[ScreenLayout::UBH + k] = -1.0f;
+    }
 }
-
 
 // Power step of the probe subspace on a sample of the columns (16 of every `stride` columns):
 //     Z += dH_S (U^T dH_S)^T,   dH = H_new - H_old
@@ -135,44 +135,23 @@ int run_refresh(onmf_ctx* c, int r, int b, const float* Hnew, const float* Hold,
     return ONMF_OK;
 }
 
-// Verdict of sweep k, for the sweep that no later sweep follows (one wave).
-__global__ __launch_bounds__(64) void screen_final_kernel(float* base, int k, float tol, float rank_cap) {
-    int* flagp = reinterpret_cast<int*>(base) + ScreenLayout::FLAG;
-    if (*flagp != 0) return;                                  // the loop ended earlier (uniform)
-    const int tid = threadIdx.x;
-    const float* set = base + ScreenLayout::SETS + (k % 3) * ScreenLayout::SETSZ;
-    float e = 0.f;
-    if (tid < 16)
-        for (int rp = 0; rp < SCREEN_REPL; ++rp) e += set[ScreenLayout::SET_P2 + rp * 16 + tid];
-#pragma unroll
-    for (int off = 8; off > 0; off >>= 1) e = fmaxf(e, __shfl_xor(e, off));
-    if (tid == 0) {
-        const double* sums = reinterpret_cast<const double*>(set + ScreenLayout::SET_SUMS);
-        double dsum = 0.0, hsum = 0.0;
-        for (int rp = 0; rp < SCREEN_REPL; ++rp) {
-            dsum += sums[2 * rp];
-            hsum += sums[2 * rp + 1];
-        }
-        float lower, upper, ubh;
-        const int verdict = screen_verdict(e, dsum, hsum, base[ScreenLayout::UBH + k], tol, rank_cap, lower,
-                                           upper, ubh);
-        float* rec = base + ScreenLayout::REC + 4 * k;
-        rec[0] = lower;
-        rec[1] = upper;
-        rec[2] = (float)(verdict + 1);
-        rec[3] = ubh;
-        if (verdict != 0) *flagp = verdict;
-    }
+// The verdicts that no sweep evaluated (a sweep evaluates the one two sweeps back): sweeps
+// k_from .. k_last in order, up to the first that ends the loop (one wave).
+__global__ __launch_bounds__(64) void screen_final_kernel(float* base, int k_from, int k_last, float tol,
+                                                          float rank_cap) {
+    if (reinterpret_cast<const int*>(base)[ScreenLayout::FLAG] != 0) return;   // the loop ended earlier (uniform)
+    float ub = base[ScreenLayout::UBH + k_from];
+    for (int j = k_from; j <= k_last; ++j)
+        if (screen_eval_wave(base, j, ub, tol, rank_cap, true) != 0) break;
 }
 
-// After the last sweep of an enqueue: put the solve's result into the caller's buffer if it ended in
-// the library's one.  The verdict records say where it ended: sweeps 0..done-1 ran, the result is
-// in buffer (done & 1), the caller's buffer is number (sub_iter & 1).  An inconclusive record means
-// the host will finish the solve: nothing to do here.
-__global__ __launch_bounds__(256) void screen_finalize_kernel(const float* base, int sub_iter,
-                                                              const float4* __restrict__ src,
+// After the last sweep of an enqueue: put the solve's result into the caller's buffer if it ended
+// elsewhere.  The verdict records say where it ended: sweeps 0..done-1 count, the result is in
+// buffer done % 3.  An inconclusive record means the host will finish the solve: nothing to do here.
+__global__ __launch_bounds__(256) void screen_finalize_kernel(const float* base, int sub_iter, const float4* hb0,
+                                                              const float4* hb1, const float4* hb2,
                                                               float4* __restrict__ dst, size_t n4) {
-    __shared__ int copy_s;
+    __shared__ int src_s;
     if (threadIdx.x == 0) {
         int done = sub_iter, undecided = 0;
         for (int i = 0; i < sub_iter; ++i) {
@@ -180,10 +159,12 @@ __global__ __launch_bounds__(256) void screen_finalize_kernel(const float* base,
             if (code == 2) { done = i + 1; break; }
             if (code != 1) { undecided = 1; break; }
         }
-        copy_s = (!undecided && ((done ^ sub_iter) & 1)) ? 1 : 0;
+        src_s = undecided ? -1 : done % 3;
     }
     __syncthreads();
-    if (!copy_s) return;
+    if (src_s < 0) return;
+    const float4* src = src_s == 0 ? hb0 : src_s == 1 ? hb1 : hb2;
+    if (src == dst) return;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
         dst[i] = src[i];
 }
@@ -310,18 +291,19 @@ int launch_screen_init(onmf_ctx* c, float* base, int r, hipStream_t s) {
     return ONMF_OK;
 }
 
-int launch_screen_final(onmf_ctx* c, float* base, int k_last, float tol, float rank_cap, hipStream_t s) {
-    hipLaunchKernelGGL(screen_final_kernel, dim3(1), dim3(64), 0, s, base, k_last, tol, rank_cap);
+int launch_screen_final(onmf_ctx* c, float* base, int k_from, int k_last, float tol, float rank_cap,
+                        hipStream_t s) {
+    hipLaunchKernelGGL(screen_final_kernel, dim3(1), dim3(64), 0, s, base, k_from, k_last, tol, rank_cap);
     HIP_TRY(c, hipGetLastError());
     return ONMF_OK;
 }
 
-int launch_screen_finalize(onmf_ctx* c, const float* base, int sub_iter, const float* src, float* dst,
+int launch_screen_finalize(onmf_ctx* c, const float* base, int sub_iter, float* const* hb, float* dst,
                            size_t n, hipStream_t s) {
-    if ((n & 3) || (((uintptr_t)src | (uintptr_t)dst) & 15))
+    if ((n & 3) || (((uintptr_t)hb[0] | (uintptr_t)hb[1] | (uintptr_t)hb[2] | (uintptr_t)dst) & 15))
         return onmf_fail(c, ONMF_ERR_ARG, "screen finalize: buffers must be 16-byte aligned multiples of 4 floats");
-    hipLaunchKernelGGL(screen_finalize_kernel, dim3(1024), dim3(256), 0, s, base, sub_iter,
-                       (const float4*)src, (float4*)dst, n / 4);
+    hipLaunchKernelGGL(screen_finalize_kernel, dim3(1024), dim3(256), 0, s, base, sub_iter, (const float4*)hb[0],
+                       (const float4*)hb[1], (const float4*)hb[2], (float4*)dst, n / 4);
     HIP_TRY(c, hipGetLastError());
     return ONMF_OK;
 }
@@ -342,8 +324,8 @@ int launch_screen_refresh(onmf_ctx* c, float* base, int r, int b, const float* H
     return ONMF_OK;
 }
 
-int launch_screen_clear_flag(onmf_ctx* c, float* base, hipStream_t s) {
-    hipLaunchKernelGGL(screen_clear_flag_kernel, dim3(1), dim3(64), 0, s, base);
+int launch_screen_clear_flag(onmf_ctx* c, float* base, int k, hipStream_t s) {
+    hipLaunchKernelGGL(screen_clear_flag_kernel, dim3(1), dim3(64), 0, s, base, k);
     HIP_TRY(c, hipGetLastError());
     return ONMF_OK;
 }

@@ -3,6 +3,8 @@
 // with step_k = 1 / (sqrt(i+10) * (Gm[k,k] + 1)).  Columns of H are independent.
 #include "common.h"
 
+#include <cmath>
+
 namespace {
 
 // ---------------------------------------------------------------------------------------------
@@ -76,21 +78,25 @@ bool sweep_tile_covers(int r, int b) {
     return (r + 15) / 16 <= 16 && (double)r * (double)b * 4.0 < 2147483000.0;
 }
 
-int launch_sweep(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm, const float* Hin,
-                 float* Hout, float alpha, float damp, int exact_cd, double* stats, int* n_groups,
+int sweep_tile_workgroups(int b) { return (b + 255) / 256; }
+
+int launch_sweep(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm, float* const* hb,
+                 float alpha, int exact_cd, int k_first, int k_count, double* stats, int* n_groups,
                  hipStream_t s, const ScreenDev* screen) {
-    const int nb = (r + 15) / 16;
+    if (k_count < 1 || k_first < 0) return onmf_fail(c, ONMF_ERR_ARG, "sweep: bad sweep range");
     const bool want_tile = sweep_tile_covers(r, b) && c->sweep_kernel != 1;
     if (!want_tile) {
         if (c->sweep_kernel >= 2)
             return onmf_fail(c, ONMF_ERR_ARG, "sweep: the tile kernel covers r <= 256 (r=%d)", r);
-        if (screen) return onmf_fail(c, ONMF_ERR_ARG, "sweep: probes need the tile kernel");
-        return launch_sweep_column(c, r, b, Gm, Cm, Hin, Hout, alpha, damp, exact_cd, stats, n_groups, s);
+        if (screen || k_count != 1) return onmf_fail(c, ONMF_ERR_ARG, "sweep: probes need the tile kernel");
+        const float damp = (float)std::sqrt((double)k_first + 10.0);
+        return launch_sweep_column(c, r, b, Gm, Cm, hb[k_first % 3], hb[(k_first + 1) % 3], alpha, damp,
+                                   exact_cd, stats, n_groups, s);
     }
     // column tiles per wave: 1 unless option value 4 asks for 2
     if (c->sweep_kernel == 4)
-        return launch_sweep_tile_ct2(c, r, b, Gm, Cm, Hin, Hout, alpha, damp, exact_cd, stats, n_groups, s,
+        return launch_sweep_tile_ct2(c, r, b, Gm, Cm, hb, alpha, exact_cd, k_first, k_count, stats, n_groups, s,
                                      screen);
-    return launch_sweep_tile_ct1(c, r, b, Gm, Cm, Hin, Hout, alpha, damp, exact_cd, stats, n_groups, s,
+    return launch_sweep_tile_ct1(c, r, b, Gm, Cm, hb, alpha, exact_cd, k_first, k_count, stats, n_groups, s,
                                  screen);
 }
