@@ -71,11 +71,12 @@ def cpu_baseline(d, r, budget_cols):
                       "%d steps of %d columns (%d sweeps in the last), %.1f s" % (d, r, n, b, len(tr), el)}
 
 
-def measured_traffic(d, r, b):
+def measured_traffic(d, r, b, sweeps_per_launch):
     """HBM bytes per sweep launch from the committed PMC passes (profiles/), when they are for this shape.
 
     PMC counters cannot be collected from inside this process; the file holds the two rocprofv3
-    passes (FETCH_SIZE, WRITE_SIZE) of the same kernel at the same shape and how they were corrected.
+    passes (FETCH_SIZE, WRITE_SIZE) of the same kernel at the same shape, per sweep, and how they
+    were corrected.  A launch of n sweeps reads H once, Cm n times and writes H n times.
     """
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_sweep_hbm_traffic.json")
     try:
@@ -83,9 +84,9 @@ def measured_traffic(d, r, b):
             rec = json.load(f)
     except (OSError, ValueError):
         return None
-    if rec.get("shape") != {"d": d, "r": r, "b": b}:
+    if rec.get("shape") != {"d": d, "r": r, "b": b} or "hbm_bytes_per_sweep_in_launch" not in rec:
         return None
-    return rec.get("hbm_bytes_per_launch")
+    return rec["hbm_bytes_first_read"] + sweeps_per_launch * rec["hbm_bytes_per_sweep_in_launch"]
 
 
 def main():
@@ -182,13 +183,17 @@ def main():
                        "sync_every": args.sync_every if world > 1 else None},
         }
         if sweep_launches > 0:
-            per_launch = 2.0 * r * r * b                      # flops of one sweep launch
+            # one launch runs one or several sweeps (all of a solve, when its grid fits the chip)
+            sweeps_per_launch = float(np.sum(sweeps_seen)) / sweep_launches
+            per_launch = 2.0 * r * r * b * sweeps_per_launch  # algorithmic flops of an average launch
             avg_ms = sweep_ms / sweep_launches
             ach = per_launch / (avg_ms * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": "code sweep (one launch = one sweep over the batch)",
+            out["roofline"] = {"bound": "mfma", "kernel": "code sweeps (one launch = the sweeps of one solve over the batch)",
                                "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": measured_traffic(d, r, b),
-                               "avg_launch_ms": avg_ms, "launches": sweep_launches}
+                               "frac": ach / PEAK_FP32_MFMA_TFLOPS,
+                               "traffic": measured_traffic(d, r, b, sweeps_per_launch),
+                               "avg_launch_ms": avg_ms, "launches": sweep_launches,
+                               "sweeps_per_launch": sweeps_per_launch}
         if not args.no_cpu_baseline:
             cols = args.cpu_cols or min(b, 4096)
             out["cpu_baseline"] = cpu_baseline(d, r, cols)

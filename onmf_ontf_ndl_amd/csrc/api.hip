@@ -436,7 +436,11 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
                 ONMF_TRY(exact_dist(c, r, b, buf[(i + 1) % 3], buf[i % 3], s, &dist, (double)rec[4 * i + 3], tol));
                 if (dist_trace) dist_trace[i] = (float)dist;
                 if (!keep_sweeping(dist, tol)) { stop = true; break; }
-                if (i + 1 < sub_iter) ONMF_TRY(launch_screen_clear_flag(c, base, i + 1, s));
+                if (i + 1 < sub_iter) {
+                    ONMF_TRY(launch_screen_clear_flag(c, base, i + 1, s));
+                    // the probes were not good enough to decide: one power step on this very move
+                    ONMF_TRY(launch_screen_refresh(c, base, r, b, buf[(i + 1) % 3], buf[i % 3], s));
+                }
                 next_start = i + 1;
                 break;
             }

@@ -93,8 +93,10 @@ int launch_sweep(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm, fl
         return launch_sweep_column(c, r, b, Gm, Cm, hb[k_first % 3], hb[(k_first + 1) % 3], alpha, damp,
                                    exact_cd, stats, n_groups, s);
     }
-    // column tiles per wave: 1 unless option value 4 asks for 2
-    if (c->sweep_kernel == 4)
+    // Column tiles per wave: option values 3 / 4 pin 1 / 2.  Otherwise 2 for the probing kernel
+    // (twice the registers per lane: its extra state fits without spills, and half the LDS operand
+    // traffic) and 1 for the plain one (4 waves per SIMD hide its shorter chain better).
+    if (c->sweep_kernel == 4 || (c->sweep_kernel != 3 && screen))
         return launch_sweep_tile_ct2(c, r, b, Gm, Cm, hb, alpha, exact_cd, k_first, k_count, stats, n_groups, s,
                                      screen);
     return launch_sweep_tile_ct1(c, r, b, Gm, Cm, hb, alpha, exact_cd, k_first, k_count, stats, n_groups, s,
