@@ -89,3 +89,35 @@ def test_host_decisions_match_when_screen_is_off(eng):
     eng.set_option(SCREEN, 1)
     Hs, ss, _ = eng.sparse_code(X, W, H0=H0, stopping_diff=0.02)
     assert sh == ss and relerr(host(Hs), host(Hh)) == 0.0
+
+
+PERSISTENT = 7
+
+
+@pytest.mark.parametrize("d,r,b,tol", [(64, 16, 500, 0.01), (200, 64, 3000, 0.05), (96, 256, 2048, 0.01),
+                                       (100, 32, 70000, 0.02), (40, 8, 1, 0.01)])
+def test_one_launch_for_all_sweeps_equals_one_launch_per_sweep(eng, d, r, b, tol):
+    """All sweeps of a solve in one launch (H in registers, verdicts two sweeps back, one sweep run
+    ahead at a stop) must return what one launch per sweep returns: same count, same code, same
+    reported bounds.  b = 70000 needs 274 workgroups: more than the chip has CUs, so that solve
+    falls back to one launch per sweep by itself."""
+    import torch
+    g = torch.Generator(device=eng.device).manual_seed(7 * d + r)
+    X = torch.rand(d, b, device=eng.device, generator=g)
+    W = torch.rand(d, r, device=eng.device, generator=g)
+    W = W / torch.clamp(torch.linalg.norm(W, dim=0), min=1.0)
+    H0 = torch.rand(r, b, device=eng.device, generator=g)
+    out = {}
+    for mode in (1, 0):
+        eng.set_option(PERSISTENT, mode)
+        try:
+            for rep in range(2):                 # second solve: probes kept from the first
+                out[(mode, rep)] = eng.sparse_code(X, W, H0=H0, alpha=0.1, sub_iter=12, stopping_diff=tol)
+        finally:
+            eng.set_option(PERSISTENT, 1)
+    eng.set_option(EXACT, 1)
+    He, se, _ = eng.sparse_code(X, W, H0=H0, alpha=0.1, sub_iter=12, stopping_diff=tol)
+    eng.set_option(EXACT, 0)
+    for key, (H, s, _) in out.items():
+        assert s == se, key
+        assert torch.equal(H, He), key
