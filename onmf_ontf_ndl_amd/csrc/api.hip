@@ -415,9 +415,13 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
                 const int code = (int)rec[4 * i + 2];     // 1 continue, 2 stop, 3 inconclusive
                 if (code == 0) {
                     HIP_TRY(c, hipMemcpy(&done, base + ScreenLayout::FLAG, sizeof(int), hipMemcpyDeviceToHost));
-                    if (done == SCREEN_FLAG_TIMEOUT)
+                    if (done == SCREEN_FLAG_TIMEOUT) {
+                        // the grid was not resident as a whole (CUs taken or masked): do not try again
+                        c->persistent_sweeps = 0;
                         return onmf_fail(c, ONMF_ERR_TIMEOUT,
-                                         "sparse_code: a sweep workgroup waited more than 2 s for the others");
+                                         "sparse_code: a sweep workgroup waited more than 2 s for the others; "
+                                         "later solves use one launch per sweep");
+                    }
                     return onmf_fail(c, ONMF_ERR_HIP, "sparse_code: sweep %d left no verdict", i);
                 }
                 done = i + 1;

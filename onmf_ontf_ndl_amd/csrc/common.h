@@ -178,22 +178,29 @@ __device__ __forceinline__ int screen_eval_wave(float* base, int j, float& ub, f
                                                 bool record) {
     const int lane = threadIdx.x & 63;
     float* set = base + ScreenLayout::SETS + j * ScreenLayout::SETSZ;
+    // all loads of the wave go out together (one memory round trip): lanes 0-15 the probe energies,
+    // lanes 16-31 the Frobenius sums
     float e = 0.f;
-    if (lane < 16)
+    double sv = 0.0;
+    if (lane < 16) {
         for (int rp = 0; rp < SCREEN_REPL; ++rp)
             e += __hip_atomic_load(set + ScreenLayout::SET_P2 + rp * 16 + lane, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
+    } else if (lane < 16 + 2 * SCREEN_REPL) {
+        // lane 16 + 2 rp + q holds sums[2 rp + q] (q = 0: sum of squared moves, 1: sum of squares of H)
+        sv = __hip_atomic_load(reinterpret_cast<double*>(set + ScreenLayout::SET_SUMS) + (lane - 16),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 #pragma unroll
     for (int off = 8; off > 0; off >>= 1) e = fmaxf(e, __shfl_xor(e, off));
+    double dsum = 0.0, hsum = 0.0;
+    for (int rp = 0; rp < SCREEN_REPL; ++rp) {                // replica order as the sums were laid out
+        dsum += __shfl(sv, 16 + 2 * rp, 64);
+        hsum += __shfl(sv, 17 + 2 * rp, 64);
+    }
     int verdict = 0;
     float ubn = ub;
     if (lane == 0) {
-        double* sums = reinterpret_cast<double*>(set + ScreenLayout::SET_SUMS);
-        double dsum = 0.0, hsum = 0.0;
-        for (int rp = 0; rp < SCREEN_REPL; ++rp) {
-            dsum += __hip_atomic_load(sums + 2 * rp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            hsum += __hip_atomic_load(sums + 2 * rp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
         float lower, upper, ubh;
         verdict = screen_verdict(e, dsum, hsum, ub, tol, rank_cap, lower, upper, ubh, ubn);
         if (record) {

@@ -79,7 +79,8 @@ __global__ __launch_bounds__(1024 / CT) void sweep_tile_kernel(
     constexpr int WAVES = NT / 64;
     float* Gs = lds;                       // NBLK swizzled 16x16 blocks of Gm
     float* steps = lds + NBLK * 256;       // 16*NB step sizes of the current sweep (0 for padded rows)
-    float* Us = steps + 16 * NB;           // PROBE: NB swizzled blocks of U^T
+    float* gdiag = steps + 16 * NB;        // diagonal of Gm
+    float* Us = gdiag + 16 * NB;           // PROBE: NB swizzled blocks of U^T
     float* p2wg = Us + NB * 256;           // PROBE: workgroup partial of the 16 probe energies
     double* sumwg = reinterpret_cast<double*>(p2wg + 16);   // PROBE: workgroup partial of the two sums
     int* verdict_s = reinterpret_cast<int*>(p2wg + 20);     // PROBE: verdict handed from wave 0 to the rest
@@ -136,6 +137,7 @@ __global__ __launch_bounds__(1024 / CT) void sweep_tile_kernel(
             }
         }
     }
+    for (int j = tid; j < 16 * NB; j += NT) gdiag[j] = j < r ? Gm[(size_t)j * r + j] : 0.f;
     if (PROBE) {
         for (int e = tid; e < NB * 256; e += NT) Us[e] = sc.base[ScreenLayout::UBLK + e];
     }
@@ -186,6 +188,8 @@ __global__ __launch_bounds__(1024 / CT) void sweep_tile_kernel(
                     const int* cnt = reinterpret_cast<const int*>(sc.base) + ScreenLayout::CNT + j;
                     const long long t0 = wall_clock64();
                     for (;;) {
+                        // (the sums are read only after the count has been seen complete: they were
+                        // all in place before its last increment)
                         if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (int)gridDim.x) break;
                         if (wall_clock64() - t0 > sc.spin_limit) {        // wave-uniform (one clock value)
                             verdict = SCREEN_FLAG_TIMEOUT;
@@ -209,7 +213,7 @@ __global__ __launch_bounds__(1024 / CT) void sweep_tile_kernel(
             for (int j = tid; j < 16 * NB; j += NT) {
                 float st = 0.f;
                 if (j < r) {
-                    const float gjj = Gm[(size_t)j * r + j];
+                    const float gjj = gdiag[j];
                     st = exact_cd ? (gjj > 0.f ? 1.0f / gjj : 0.f) : rdamp / (gjj + 1.0f);
                 }
                 steps[j] = st;
@@ -442,7 +446,7 @@ int run_tile(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm, float*
              int exact_cd, int k_first, int k_count, double* stats, int* n_groups, const ScreenDev& sc,
              hipStream_t s) {
     constexpr int NBLK = HALF ? NB * (NB + 1) / 2 : NB * NB;
-    constexpr size_t lds = sizeof(float) * ((size_t)NBLK * 256 + NB * 16 + (PROBE ? (NB * 256 + 16 + 4 + 4) : 0));
+    constexpr size_t lds = sizeof(float) * ((size_t)NBLK * 256 + 2 * NB * 16 + (PROBE ? (NB * 256 + 16 + 4 + 4) : 0));
     static_assert(lds <= 160 * 1024, "Gm blocks do not fit the LDS");
     static bool attr_done = false;
     if (!attr_done) {
