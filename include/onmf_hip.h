@@ -111,6 +111,52 @@ int onmf_code_accumulate(onmf_ctx* ctx, int r, int n, float* code, const int64_t
 int onmf_unfold3(onmf_ctx* ctx, int n0, int n1, int n2, const float* T, int mode, int transpose,
                  float* out, void* stream);
 
+/*
+ * Many independent one-column solves in one call: what reconstruct_image_color does patch by patch,
+ * image_reconstruction.py:375-384 - update_code_within_radius(patch, W, H0=None, r=None, alpha,
+ * sub_iter, stopping_diff) (src/onmf.py:233-271) once per d x 1 patch.  Column c of X is solved with
+ * its OWN stopping test (for one column the spectral norms of src/onmf.py:265 are vector 2-norms):
+ * it takes part in sweep i only while dist_c of sweep i-1 exceeded stopping_diff.
+ *   H0 == NULL: U[0,1) from the device generator (the reference draws rand(r,1) per patch, :245-246;
+ *               a host that needs that stream passes H0 with one draw per column).
+ *   sweeps_each (device int32[b], nullable): sweeps each column ran.
+ * Asynchronous on `stream` (returns no host scalars).  H may be H0 (in place).
+ */
+int onmf_sparse_code_each(onmf_ctx* ctx, int d, int r, int b, const float* X, int ldx, const float* W,
+                          const float* H0, uint64_t seed, float alpha, int sub_iter,
+                          float stopping_diff, int coder_mode, float* H, int32_t* sweeps_each,
+                          void* stream);
+
+/* R = W H (d x b, leading dimension ldr): np.dot(self.W, code), image_reconstruction.py:352, :385. */
+int onmf_patch_product(onmf_ctx* ctx, int d, int r, int b, const float* W, const float* H, float* R,
+                       int ldr, void* stream);
+
+/*
+ * Patches of an image as the columns of X (d x b, d = k*k*ch).  img: h x w x ch, C order; feature
+ * order = window.reshape(-1), i.e. f = (x0*k + x1)*ch + cc.
+ *   corners != NULL: device int32[2*b], (row, column) of each patch's top-left corner -
+ *               extract_random_patches, image_reconstruction.py:173-206 (the host draws the corners,
+ *               :185-186 / :197-198, so the RNG stream stays the caller's).
+ *   corners == NULL: the regular grid of grid_rows x grid_cols patches `stride` pixels apart, row by
+ *               row (b = grid_rows*grid_cols) - sklearn extract_patches_2d as used for reconstruction,
+ *               image_reconstruction.py:163-166 (stride 1, all patches), and the window loop of
+ *               reconstruct_image_color, :375-378.
+ */
+int onmf_extract_patches(onmf_ctx* ctx, const float* img, int h, int w, int ch, int k,
+                         const int32_t* corners, int b, int grid_rows, int grid_cols, int stride,
+                         float* X, int ldx, void* stream);
+
+/*
+ * Overlap-average of patch values back into an image: the painting loop of reconstruct_image_color,
+ * image_reconstruction.py:388-392 (running mean over the patches that cover a pixel), and sklearn
+ * reconstruct_from_patches_2d at :354.  R: d x (grid_rows*grid_cols) patch values (leading dimension
+ * ldr) on the same grid as onmf_extract_patches.  out: h x w x ch; pixels that no patch covers are 0
+ * (the reference's canvas starts as zeros).  count (nullable): h x w, patches over each pixel
+ * (A_overlap_count).
+ */
+int onmf_fold_patches(onmf_ctx* ctx, const float* R, int ldr, int h, int w, int ch, int k,
+                      int grid_rows, int grid_cols, int stride, float* out, float* count, void* stream);
+
 /* U[0,1) fill, the device stand-in for np.random.rand (src/onmf.py:190, :246). */
 int onmf_fill_uniform(onmf_ctx* ctx, float* out, size_t n, uint64_t seed, void* stream);
 
@@ -137,7 +183,7 @@ double onmf_host_lambda_max(const float* S_host, int n);
  *                          enqueued without host round trips; the full test runs only where the
  *                          bounds straddle stopping_diff.  0: one host decision per sweep.
  *   ONMF_OPT_DICT_KERNEL   0 = pick by shape, 1 = cooperating one-wave workgroups (any d <= 16384),
- *                          2 = one workgroup (d <= 4096).
+ *                          2 = one workgroup (d <= 1024).
  *   ONMF_OPT_PERSISTENT_SWEEPS != 0 (default): with the screened stopping test, run all sweeps of
  *                          a solve in one launch when its grid (one workgroup per 256 columns)
  *                          fits the chip's CUs; 0: one launch per sweep.

@@ -676,6 +676,87 @@ int onmf_unfold3(onmf_ctx* c, int n0, int n1, int n2, const float* T, int mode, 
     return ONMF_OK;
 }
 
+int onmf_sparse_code_each(onmf_ctx* c, int d, int r, int b, const float* X, int ldx, const float* W,
+                          const float* H0, uint64_t seed, float alpha, int sub_iter, float stopping_diff,
+                          int coder_mode, float* H, int32_t* sweeps_each, void* stream) {
+    if (!c) return ONMF_ERR_ARG;
+    if (d <= 0 || r <= 0 || b <= 0 || !X || !W || !H || ldx < b || sub_iter < 0)
+        return onmf_fail(c, ONMF_ERR_ARG, "sparse_code_each: bad arguments (d=%d r=%d b=%d ldx=%d)", d, r, b, ldx);
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t rb = (size_t)r * b;
+    ONMF_TRY(onmf_reserve(c, c->gram, (size_t)r * r * sizeof(float), "Gm"));
+    ONMF_TRY(onmf_reserve(c, c->cm, rb * sizeof(float), "Cm"));
+    float* Gm = (float*)c->gram.p;
+    float* Cm = (float*)c->cm.p;
+    // Gm = W^T W, Cm = W^T X (src/onmf.py:242-243), the start (src/onmf.py:245-248), then every sweep
+    // of every column in one launch
+    ONMF_TRY(launch_gemm(c, true, true, r, r, d, W, r, W, r, 1.f, 0.f, nullptr, Gm, r, s));
+    ONMF_TRY(launch_gemm(c, true, true, r, b, d, W, r, X, ldx, 1.f, 0.f, nullptr, Cm, b, s));
+    if (H0) {
+        if (H0 != H) HIP_TRY(c, hipMemcpyAsync(H, H0, rb * sizeof(float), hipMemcpyDeviceToDevice, s));
+    } else if (launch_fill_uniform(H, rb, seed, s) != ONMF_OK) {
+        return onmf_fail(c, ONMF_ERR_HIP, "sparse_code_each: fill launch failed");
+    }
+    if (sub_iter == 0) {
+        if (sweeps_each) HIP_TRY(c, hipMemsetAsync(sweeps_each, 0, (size_t)b * sizeof(int32_t), s));
+        return ONMF_OK;
+    }
+    EachStop es = {stopping_diff, sweeps_each};
+    return launch_sweep_each(c, r, b, Gm, Cm, H, alpha, coder_mode == ONMF_CODER_EXACT_CD, sub_iter, es, s);
+}
+
+int onmf_patch_product(onmf_ctx* c, int d, int r, int b, const float* W, const float* H, float* R, int ldr,
+                       void* stream) {
+    if (!c) return ONMF_ERR_ARG;
+    if (d <= 0 || r <= 0 || b <= 0 || !W || !H || !R || ldr < b)
+        return onmf_fail(c, ONMF_ERR_ARG, "patch_product: bad arguments");
+    HIP_TRY(c, hipSetDevice(c->device));
+    return launch_gemm(c, false, true, d, b, r, W, r, H, b, 1.f, 0.f, nullptr, R, ldr, (hipStream_t)stream);
+}
+
+static int patch_args(onmf_ctx* c, const char* what, int h, int w, int ch, int k, int grid_rows, int grid_cols,
+                      int stride) {
+    if (h <= 0 || w <= 0 || ch <= 0 || k <= 0 || k > h || k > w)
+        return onmf_fail(c, ONMF_ERR_ARG, "%s: bad image / patch size (h=%d w=%d ch=%d k=%d)", what, h, w, ch, k);
+    if ((double)k * k * ch > 65535.0) return onmf_fail(c, ONMF_ERR_ARG, "%s: patch too large", what);
+    if (grid_rows > 0 || grid_cols > 0) {
+        if (stride <= 0 || grid_rows <= 0 || grid_cols <= 0 || (long long)(grid_rows - 1) * stride + k > h ||
+            (long long)(grid_cols - 1) * stride + k > w)
+            return onmf_fail(c, ONMF_ERR_ARG, "%s: the %d x %d grid (stride %d) leaves the image", what, grid_rows,
+                             grid_cols, stride);
+    }
+    return ONMF_OK;
+}
+
+int onmf_extract_patches(onmf_ctx* c, const float* img, int h, int w, int ch, int k, const int32_t* corners,
+                         int b, int grid_rows, int grid_cols, int stride, float* X, int ldx, void* stream) {
+    if (!c) return ONMF_ERR_ARG;
+    if (!img || !X || b <= 0 || ldx < b) return onmf_fail(c, ONMF_ERR_ARG, "extract_patches: bad arguments");
+    if (corners) grid_rows = grid_cols = 0;
+    ONMF_TRY(patch_args(c, "extract_patches", h, w, ch, k, grid_rows, grid_cols, stride));
+    if (!corners && (long long)grid_rows * grid_cols != b)
+        return onmf_fail(c, ONMF_ERR_ARG, "extract_patches: b=%d is not the grid's %d x %d", b, grid_rows, grid_cols);
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (launch_patch_extract(img, h, w, ch, k, (const int*)corners, b, corners ? 1 : grid_cols, corners ? 1 : stride,
+                             X, ldx, (hipStream_t)stream) != ONMF_OK)
+        return onmf_fail(c, ONMF_ERR_HIP, "extract_patches: launch failed");
+    return ONMF_OK;
+}
+
+int onmf_fold_patches(onmf_ctx* c, const float* R, int ldr, int h, int w, int ch, int k, int grid_rows,
+                      int grid_cols, int stride, float* out, float* count, void* stream) {
+    if (!c) return ONMF_ERR_ARG;
+    if (!R || !out || grid_rows <= 0 || grid_cols <= 0 || (long long)grid_rows * grid_cols > ldr)
+        return onmf_fail(c, ONMF_ERR_ARG, "fold_patches: bad arguments");
+    ONMF_TRY(patch_args(c, "fold_patches", h, w, ch, k, grid_rows, grid_cols, stride));
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (launch_patch_fold(R, ldr, h, w, ch, k, grid_rows, grid_cols, stride, out, count, (hipStream_t)stream) !=
+        ONMF_OK)
+        return onmf_fail(c, ONMF_ERR_HIP, "fold_patches: launch failed");
+    return ONMF_OK;
+}
+
 int onmf_fill_uniform(onmf_ctx* c, float* out, size_t n, uint64_t seed, void* stream) {
     if (!c) return ONMF_ERR_ARG;
     if (!out && n) return onmf_fail(c, ONMF_ERR_ARG, "fill_uniform: null output");

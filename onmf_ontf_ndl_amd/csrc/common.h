@@ -98,6 +98,12 @@ struct ScreenDev {
     long long spin_limit;    // bound (100 MHz ticks) on waiting for the other workgroups' sums
 };
 
+// Per-column stopping (many independent one-column solves in one launch).
+struct EachStop {
+    float tol;           // a column goes on while ||h_new - h_old|| / ||h_old|| > tol
+    int* sweeps;         // device int[b] or null: sweeps each column ran
+};
+
 // Gauss-Seidel sweeps k_first .. k_first + k_count - 1 over all rows: sweep k reads hb[k % 3] (only
 // the first of a launch actually loads it) and writes hb[(k + 1) % 3].  stats (device, 2 doubles per
 // wave) receives sum((new - old)^2) and sum(old^2) partials of the LAST sweep run; *n_groups = number
@@ -112,8 +118,20 @@ int launch_sweep_tile_ct2(onmf_ctx* c, int r, int b, const float* Gm, const floa
 int launch_sweep(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm, float* const* hb,
                  float alpha, int exact_cd, int k_first, int k_count, double* stats, int* n_groups,
                  hipStream_t s, const ScreenDev* screen = nullptr);
+// Sweeps 0 .. sub_iter-1 in one launch, every column with its own stopping test; H in place.
+int launch_sweep_each(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm, float* H, float alpha,
+                      int exact_cd, int sub_iter, EachStop es, hipStream_t s);
+int launch_sweep_tile_each(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm, float* H, float alpha,
+                           int exact_cd, int sub_iter, EachStop es, hipStream_t s);
 int sweep_tile_workgroups(int b);
 bool sweep_tile_covers(int r, int b);
+
+// Image <-> patch matrix (patches.hip).  corners: device int[2*b] (row, column) pairs, or null for the
+// regular grid of grid_cols patches per row, `stride` pixels apart.
+int launch_patch_extract(const float* img, int h, int w, int ch, int k, const int* corners, int b, int grid_cols,
+                         int stride, float* X, int ldx, hipStream_t s);
+int launch_patch_fold(const float* R, int ldr, int h, int w, int ch, int k, int grid_rows, int grid_cols, int stride,
+                      float* out, float* count, hipStream_t s);
 
 // Stopping-test screen: state layout and kernels.
 constexpr int SCREEN_MAX_SWEEPS = 64;

@@ -53,7 +53,71 @@ __global__ __launch_bounds__(64) void sweep_column_kernel(int r, int b, const fl
     }
 }
 
+// The same with every sweep of the solve in one launch and a stopping test per column (see the tile
+// kernel's per-column mode): a lane stops updating once its own column has converged.
+__global__ __launch_bounds__(64) void sweep_column_each_kernel(int r, int b, const float* __restrict__ Gm,
+                                                               const float* __restrict__ Cm, float* H,
+                                                               float alpha, int exact_cd, int sub_iter,
+                                                               EachStop es) {
+    extern __shared__ __attribute__((aligned(16))) float hs[];
+    const int lane = threadIdx.x;
+    const int c = blockIdx.x * 64 + lane;
+    const bool valid = c < b;
+    for (int k = 0; k < r; ++k) hs[k * 64 + lane] = valid ? H[(size_t)k * b + c] : 0.f;
+    bool active = valid;
+    int n = 0;
+    for (int i = 0; i < sub_iter; ++i) {
+        if (__ballot(active) == 0) break;
+        const float rdamp = 1.0f / (float)sqrt((double)i + 10.0);
+        float dsum = 0.f, hsum = 0.f;
+        for (int k = 0; k < r; ++k) {
+            const float* __restrict__ gk = Gm + (size_t)k * r;
+            float dot = 0.f;
+            for (int j = 0; j < r; ++j) dot = fmaf(gk[j], hs[j * 64 + lane], dot);
+            const float gkk = gk[k];
+            const float step = exact_cd ? (gkk > 0.f ? 1.0f / gkk : 0.f) : rdamp / (gkk + 1.0f);
+            const float hold = hs[k * 64 + lane];
+            const float cm = valid ? Cm[(size_t)k * b + c] : 0.f;
+            const float grad = dot - cm + alpha;
+            const float hnew = active ? fmaxf(fmaf(-grad, step, hold), 0.f) : hold;
+            hs[k * 64 + lane] = hnew;
+            const float dl = hnew - hold;
+            dsum = fmaf(dl, dl, dsum);
+            hsum = fmaf(hold, hold, hsum);
+        }
+        if (active) {
+            ++n;
+            active = sqrt((double)dsum) / sqrt((double)hsum) > (double)es.tol;
+        }
+    }
+    if (valid) {
+        for (int k = 0; k < r; ++k) H[(size_t)k * b + c] = hs[k * 64 + lane];
+        if (es.sweeps != nullptr) es.sweeps[c] = n;
+    }
+}
+
 }  // namespace
+
+int launch_sweep_each(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm, float* H, float alpha,
+                      int exact_cd, int sub_iter, EachStop es, hipStream_t s) {
+    if (sub_iter < 1) return ONMF_OK;
+    if (sweep_tile_covers(r, b) && c->sweep_kernel != 1)
+        return launch_sweep_tile_each(c, r, b, Gm, Cm, H, alpha, exact_cd, sub_iter, es, s);
+    if (c->sweep_kernel >= 2)
+        return onmf_fail(c, ONMF_ERR_ARG, "sweep: the tile kernel covers r <= 256 (r=%d)", r);
+    const size_t lds = (size_t)r * 64 * sizeof(float);
+    if (lds > 160 * 1024) return onmf_fail(c, ONMF_ERR_ARG, "sweep: r=%d needs %zu B of LDS", r, lds);
+    static size_t attr_bytes = 0;
+    if (lds > attr_bytes) {
+        HIP_TRY(c, hipFuncSetAttribute((const void*)sweep_column_each_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_bytes = lds;
+    }
+    hipLaunchKernelGGL(sweep_column_each_kernel, dim3((b + 63) / 64), dim3(64), lds, s, r, b, Gm, Cm, H, alpha,
+                       exact_cd, sub_iter, es);
+    HIP_TRY(c, hipGetLastError());
+    return ONMF_OK;
+}
 
 static int launch_sweep_column(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm,
                                const float* Hin, float* Hout, float alpha, float damp, int exact_cd,

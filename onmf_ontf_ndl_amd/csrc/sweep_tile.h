@@ -68,11 +68,20 @@ __device__ __forceinline__ float row_sum16(float x) {
 // vain - it wrote the third of three rotating H buffers, and both buffers of the stopping sweep are
 // intact.  The waits are bounded; a grid that is not resident as a whole would make them fail, so
 // the host launches k_count > 1 only for grids that fit the chip.
-template <int NB, bool HALF, bool PROBE, int CT>
+//
+// EACH = true is the solve of many independent one-column problems in one launch (the reference
+// codes an image patch by patch, image_reconstruction.py:384, each call with its own stopping
+// test): a column takes part in sweep k only while its own  ||h_new - h_old|| / ||h_old||  of the
+// sweep before exceeds es.tol - for one column the spectral norms of src/onmf.py:265 are vector
+// norms.  A column that has stopped runs with step 0 (exact no-op); a wave whose 16 columns have all
+// stopped skips the arithmetic.  Nothing is exchanged between workgroups, H is loaded once and stored
+// once (in place is fine), and es.sweeps receives the number of sweeps each column ran.
+template <int NB, bool HALF, bool PROBE, int CT, bool EACH = false>
 __global__ __launch_bounds__(1024 / CT) void sweep_tile_kernel(
     int r, int b, const float* __restrict__ Gm, const float* __restrict__ Cm, float* hb0, float* hb1,
     float* hb2, float alpha, int exact_cd, int k_first, int k_count, double* __restrict__ stats,
-    ScreenDev sc) {
+    ScreenDev sc, EachStop es) {
+    static_assert(!EACH || (!PROBE && CT == 1), "per-column stopping: plain kernel, one tile per wave");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NBLK = HALF ? NB * (NB + 1) / 2 : NB * NB;
     constexpr int NT = 1024 / CT;          // threads per workgroup
@@ -177,6 +186,8 @@ __global__ __launch_bounds__(1024 / CT) void sweep_tile_kernel(
                         __builtin_amdgcn_raw_buffer_load_b32(rs_h, voff[ct], (16 * J + t) * b * 4, 0));
     }
     float ub = PROBE ? sc.base[ScreenLayout::UBH + sc.v_first] : -1.0f;    // bound carried by wave 0
+    bool active = true;                    // EACH: this lane's column is still iterating
+    int col_sweeps = 0;
 
     for (int k = k_first; k < k_first + k_count; ++k) {
         if (PROBE) {
@@ -230,6 +241,12 @@ __global__ __launch_bounds__(1024 / CT) void sweep_tile_kernel(
 
         // (opaque per-sweep copies of the lane coordinates: hoisted out of this loop, the hundreds of
         // LDS addresses derived from them would each occupy a register for the whole kernel)
+        if (EACH) {
+            if (__ballot(active) == 0) {   // wave-uniform: all 16 columns are done
+                if (k + 1 < k_first + k_count) __syncthreads();
+                continue;
+            }
+        }
         int lane_k = threadIdx.x;
         asm volatile("" : "+v"(lane_k));
         const int c = lane_k & 15, g = (lane_k >> 4) & 3, sw_c = swz(c);
@@ -305,7 +322,11 @@ __global__ __launch_bounds__(1024 / CT) void sweep_tile_kernel(
             // acc = gradient of rows 4g+t of block K (without the in-block corrections)
             float acc[CT][4], hold4[CT][4];
             const float4 st4 = *reinterpret_cast<const float4*>(steps + 16 * K + 4 * g);
-            const float st[4] = {st4.x, st4.y, st4.z, st4.w};
+            float st[4] = {st4.x, st4.y, st4.z, st4.w};
+            if (EACH) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) st[t] = active ? st[t] : 0.f;
+            }
     #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
     #pragma unroll
@@ -372,12 +393,14 @@ __global__ __launch_bounds__(1024 / CT) void sweep_tile_kernel(
             asm volatile("" : "+v"(dsum));     // keep the running sum current (no deferred chain)
             __builtin_amdgcn_s_setprio(0);
             // rows of block K are final: store them now, under the remaining blocks' arithmetic
+            if (!EACH) {
     #pragma unroll
-            for (int ct = 0; ct < CT; ++ct)
+                for (int ct = 0; ct < CT; ++ct)
     #pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(h[ct][K][t]), rs_o, voff[ct],
-                                                          (16 * K + t) * bk * 4, 0);
+                    for (int t = 0; t < 4; ++t)
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(h[ct][K][t]), rs_o, voff[ct],
+                                                              (16 * K + t) * bk * 4, 0);
+            }
             if (PROBE) {
                 const float4 u4 = *reinterpret_cast<const float4*>(Us + K * 256 + c * 16 + 4 * (g ^ sw_c));
     #pragma unroll
@@ -390,6 +413,21 @@ __global__ __launch_bounds__(1024 / CT) void sweep_tile_kernel(
             }
         }
 
+        if (EACH) {
+            // the column's own test: its rows live in lanes c, c+16, c+32, c+48
+            float dc = dsum, hc = hsum;
+            dc += __shfl_xor(dc, 16);
+            hc += __shfl_xor(hc, 16);
+            dc += __shfl_xor(dc, 32);
+            hc += __shfl_xor(hc, 32);
+            if (active) {
+                ++col_sweeps;
+                // 0/0 (NaN) ends the loop, x/0 (+inf) does not: the comparison of src/onmf.py:252
+                active = sqrt((double)dc) / sqrt((double)hc) > (double)es.tol;
+            }
+            if (k + 1 < k_first + k_count) __syncthreads();    // the next sweep rewrites the step sizes
+            continue;
+        }
         double ds = dsum, hh = hsum;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
@@ -439,26 +477,40 @@ __global__ __launch_bounds__(1024 / CT) void sweep_tile_kernel(
             __syncthreads();               // the next sweep rewrites the step sizes
         }
     }
+    if (EACH) {
+        const int kend = k_first + k_count;
+        float* hout = (kend % 3 == 0) ? hb0 : (kend % 3 == 1) ? hb1 : hb2;
+        const auto rs_o = __builtin_amdgcn_make_buffer_rsrc((void*)hout, 0, nbytes, 0x00020000);
+#pragma unroll
+        for (int J = 0; J < NB; ++J)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(h[0][J][t]), rs_o, voff[0], (16 * J + t) * b * 4, 0);
+        if (es.sweeps != nullptr && g_lane == 0) {
+            const int col = (blockIdx.x * WAVES + wave) * 16 + c_lane;
+            if (col < b) es.sweeps[col] = col_sweeps;
+        }
+    }
 }
 
-template <int NB, bool HALF, bool PROBE, int CT>
+template <int NB, bool HALF, bool PROBE, int CT, bool EACH = false>
 int run_tile(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm, float* const* hb, float alpha,
              int exact_cd, int k_first, int k_count, double* stats, int* n_groups, const ScreenDev& sc,
-             hipStream_t s) {
+             hipStream_t s, EachStop es = EachStop{}) {
     constexpr int NBLK = HALF ? NB * (NB + 1) / 2 : NB * NB;
     constexpr size_t lds = sizeof(float) * ((size_t)NBLK * 256 + 2 * NB * 16 + (PROBE ? (NB * 256 + 16 + 4 + 4) : 0));
     static_assert(lds <= 160 * 1024, "Gm blocks do not fit the LDS");
     static bool attr_done = false;
     if (!attr_done) {
-        HIP_TRY(c, hipFuncSetAttribute((const void*)sweep_tile_kernel<NB, HALF, PROBE, CT>,
+        HIP_TRY(c, hipFuncSetAttribute((const void*)sweep_tile_kernel<NB, HALF, PROBE, CT, EACH>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
     constexpr int NT = 1024 / CT;
     const int wgs = (b + TILE_COLS_PER_WG - 1) / TILE_COLS_PER_WG;
     *n_groups = wgs * (NT / 64);
-    hipLaunchKernelGGL((sweep_tile_kernel<NB, HALF, PROBE, CT>), dim3(wgs), dim3(NT), lds, s, r, b, Gm, Cm,
-                       hb[0], hb[1], hb[2], alpha, exact_cd, k_first, k_count, stats, sc);
+    hipLaunchKernelGGL((sweep_tile_kernel<NB, HALF, PROBE, CT, EACH>), dim3(wgs), dim3(NT), lds, s, r, b, Gm, Cm,
+                       hb[0], hb[1], hb[2], alpha, exact_cd, k_first, k_count, stats, sc, es);
     HIP_TRY(c, hipGetLastError());
     return ONMF_OK;
 }

@@ -183,6 +183,74 @@ class Engine:
         _lib.check(rc, self.ctx, "onmf_unfold3")
         return out
 
+    # ------------------------------------------------------------------ images either side of the path
+    def sparse_code_each(self, X, W, H0=None, alpha=0.0, sub_iter=10, stopping_diff=0.01, seed=None,
+                         mode=_lib.CODER_DAMPED, want_sweeps=False):
+        """One independent solve per column, each with its own stopping test
+        (image_reconstruction.py:384 calls onmf.py:233-271 once per patch).  No host round trip."""
+        d, b = X.shape
+        r = W.shape[1]
+        if W.shape[0] != d:
+            raise ValueError("W has %d rows, X has %d" % (W.shape[0], d))
+        if H0 is not None and tuple(H0.shape) != (r, b):
+            raise ValueError("H0 must be (%d, %d)" % (r, b))
+        H = self.empty(r, b)
+        sweeps = self.torch.empty(b, dtype=self.torch.int32, device=self.device) if want_sweeps else None
+        if seed is None:
+            seed = self.next_seed()
+        rc = self.lib.onmf_sparse_code_each(self.ctx, d, r, b, _ptr(X), X.stride(0), _ptr(W), _ptr(H0),
+                                            C.c_uint64(seed), float(alpha), int(sub_iter),
+                                            float(stopping_diff), int(mode), _ptr(H), _ptr(sweeps),
+                                            self.stream())
+        _lib.check(rc, self.ctx, "onmf_sparse_code_each")
+        return (H, sweeps) if want_sweeps else H
+
+    def patch_product(self, W, H):
+        """W @ H (image_reconstruction.py:352, :385)."""
+        d, r = W.shape
+        b = H.shape[1]
+        R = self.empty(d, b)
+        rc = self.lib.onmf_patch_product(self.ctx, d, r, b, _ptr(W), _ptr(H), _ptr(R), b, self.stream())
+        _lib.check(rc, self.ctx, "onmf_patch_product")
+        return R
+
+    def extract_patches(self, img, k, corners=None, grid=None, stride=1):
+        """Patch matrix (k*k*ch x b) of an (h, w[, ch]) image: ``corners`` (b x 2 top-left corners,
+        image_reconstruction.py:173-206) or ``grid`` = (rows, cols) windows ``stride`` apart."""
+        h, w = img.shape[0], img.shape[1]
+        ch = img.shape[2] if img.dim() == 3 else 1
+        if corners is not None:
+            corners = self.dev(corners, self.torch.int32)
+            if corners.dim() != 2 or corners.shape[1] != 2:
+                raise ValueError("corners must be (b, 2)")
+            if corners.numel() and (int(corners.min()) < 0 or int(corners[:, 0].max()) > h - k or
+                                    int(corners[:, 1].max()) > w - k):
+                raise ValueError("a patch corner lies outside the image")
+            b, gr, gc = corners.shape[0], 0, 0
+        else:
+            gr, gc = grid
+            b = gr * gc
+        X = self.empty(k * k * ch, b)
+        rc = self.lib.onmf_extract_patches(self.ctx, _ptr(img), h, w, ch, int(k), _ptr(corners), b, gr, gc,
+                                           int(stride), _ptr(X), b, self.stream())
+        _lib.check(rc, self.ctx, "onmf_extract_patches")
+        return X
+
+    def fold_patches(self, R, shape, k, grid, stride=1):
+        """Overlap-average of patch values (d x b on ``grid``) into an image of ``shape``
+        (image_reconstruction.py:354, :388-392).  Returns (image, overlap count)."""
+        h, w = int(shape[0]), int(shape[1])
+        ch = int(shape[2]) if len(shape) == 3 else 1
+        gr, gc = grid
+        if R.shape[0] != k * k * ch or R.shape[1] != gr * gc:
+            raise ValueError("R must be (%d, %d)" % (k * k * ch, gr * gc))
+        out = self.empty(*shape)
+        count = self.empty(h, w)
+        rc = self.lib.onmf_fold_patches(self.ctx, _ptr(R), R.stride(0), h, w, ch, int(k), gr, gc, int(stride),
+                                        _ptr(out), _ptr(count), self.stream())
+        _lib.check(rc, self.ctx, "onmf_fold_patches")
+        return out, count
+
     def rand(self, rows, cols, seed=None):
         out = self.empty(rows, cols)
         if seed is None:

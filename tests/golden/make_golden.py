@@ -274,7 +274,45 @@ def g9_lasso():
     save("g9_lasso", **out)
 
 
+def g10_image():
+    """Patch matrix and overlap average from scikit-learn (the calls of image_reconstruction.py:163-166
+    and :354), and one reference coder call per window as image_reconstruction.py:384 makes them
+    (alpha=1, sub_iter=10, stopping_diff=0.01, H0=None drawn from the global generator)."""
+    from sklearn.feature_extraction.image import extract_patches_2d, reconstruct_from_patches_2d
+    rs = np.random.RandomState(23)
+    k = 4
+    grey = rs.rand(11, 9)
+    patches = extract_patches_2d(grey, (k, k))
+    X_grey = patches.reshape(len(patches), -1).T
+    vals = rs.rand(*patches.shape)
+    fold_grey = reconstruct_from_patches_2d(vals, grey.shape)
+    color = rs.rand(9, 10, 3)
+    W = rs.rand(k * k * 3, 6)
+    W /= np.linalg.norm(W, axis=0)
+    np.random.seed(77)
+    codes, starts, sweeps, codes_loose, sweeps_loose = [], [], [], [], []
+    for i in range(0, color.shape[0] - k, 2):
+        for j in range(0, color.shape[1] - k, 2):
+            patch = color[i:i + k, j:j + k, :].reshape((-1, 1))
+            state = np.random.get_state()
+            starts.append(np.random.rand(W.shape[1], 1))     # the draw the call below repeats
+            np.random.set_state(state)
+            with NormTap() as tap:
+                codes.append(update_code_within_radius(patch, W, H0=None, r=None, alpha=1, sub_iter=10,
+                                                       stopping_diff=0.01))
+            sweeps.append(len(tap.dists()))
+            # the same start under a looser test, so that the windows stop after different sweep counts
+            with NormTap() as tap:
+                codes_loose.append(update_code_within_radius(patch, W, H0=starts[-1].copy(), r=None, alpha=1,
+                                                             sub_iter=10, stopping_diff=0.03))
+            sweeps_loose.append(len(tap.dists()))
+    save("g10_image", k=np.int64(k), grey=grey, X_grey=X_grey, vals=vals.reshape(len(vals), -1).T,
+         fold_grey=fold_grey, color=color, W=W, stride=np.int64(2), H0=np.hstack(starts),
+         code=np.hstack(codes), sweeps=np.array(sweeps), tol_loose=np.float64(0.03),
+         code_loose=np.hstack(codes_loose), sweeps_loose=np.array(sweeps_loose))
+
+
 if __name__ == "__main__":
     for fn in (g1_code, g2_dict, g3_steps, g4_train_warm, g5_subsample, g6_full_code,
-               g7_beta_alpha, g8_stream, g9_lasso):
+               g7_beta_alpha, g8_stream, g9_lasso, g10_image):
         fn()
