@@ -157,6 +157,15 @@ int onmf_extract_patches(onmf_ctx* ctx, const float* img, int h, int w, int ch, 
 int onmf_fold_patches(onmf_ctx* ctx, const float* R, int ldr, int h, int w, int ch, int k,
                       int grid_rows, int grid_cols, int stride, float* out, float* count, void* stream);
 
+/*
+ * Surrogate loss of the current dictionary against the aggregates,
+ *   tr(W A W^T) - 2 tr(W B) + tr(C)      (ising_reconstruction.py:133, :164),
+ * accumulated in double.  C may be NULL (its trace is then left out).  *loss is a HOST double: the
+ * call synchronises `stream`.
+ */
+int onmf_surrogate_loss(onmf_ctx* ctx, int d, int r, const float* W, const float* A, const float* B,
+                        const float* C, double* loss, void* stream);
+
 /* U[0,1) fill, the device stand-in for np.random.rand (src/onmf.py:190, :246). */
 int onmf_fill_uniform(onmf_ctx* ctx, float* out, size_t n, uint64_t seed, void* stream);
 

@@ -757,6 +757,28 @@ int onmf_fold_patches(onmf_ctx* c, const float* R, int ldr, int h, int w, int ch
     return ONMF_OK;
 }
 
+int onmf_surrogate_loss(onmf_ctx* c, int d, int r, const float* W, const float* A, const float* B,
+                        const float* Cagg, double* loss, void* stream) {
+    if (!c) return ONMF_ERR_ARG;
+    if (d <= 0 || r <= 0 || !W || !A || !B || !loss) return onmf_fail(c, ONMF_ERR_ARG, "surrogate_loss: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(c, hipSetDevice(c->device));
+    constexpr int BLOCKS = 64;
+    ONMF_TRY(onmf_reserve(c, c->qt, (size_t)r * d * sizeof(float), "W A"));
+    ONMF_TRY(onmf_reserve(c, c->stats, BLOCKS * sizeof(double), "loss partials"));
+    ONMF_TRY(onmf_reserve_pinned(c, BLOCKS * sizeof(double)));
+    float* Q = (float*)c->qt.p;
+    ONMF_TRY(launch_gemm(c, false, true, d, r, r, W, r, A, r, 1.f, 0.f, nullptr, Q, r, s));
+    if (launch_surrogate_partials(d, r, Q, W, B, Cagg, (double*)c->stats.p, BLOCKS, s) != ONMF_OK)
+        return onmf_fail(c, ONMF_ERR_HIP, "surrogate_loss: launch failed");
+    HIP_TRY(c, hipMemcpyAsync(c->pinned, c->stats.p, BLOCKS * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    double total = 0.0;
+    for (int i = 0; i < BLOCKS; ++i) total += ((const double*)c->pinned)[i];
+    *loss = total;
+    return ONMF_OK;
+}
+
 int onmf_fill_uniform(onmf_ctx* c, float* out, size_t n, uint64_t seed, void* stream) {
     if (!c) return ONMF_ERR_ARG;
     if (!out && n) return onmf_fail(c, ONMF_ERR_ARG, "fill_uniform: null output");

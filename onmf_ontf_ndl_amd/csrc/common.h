@@ -265,6 +265,8 @@ int launch_sub(float* out, const float* a, const float* b, size_t n, hipStream_t
 int launch_unfold3(int n0, int n1, int n2, const float* T, int mode, int transpose, float* out,
                    hipStream_t s);
 int launch_transpose(int rows, int cols, const float* in, float* out, hipStream_t s);
+int launch_surrogate_partials(int d, int r, const float* Q, const float* W, const float* B, const float* Cagg,
+                              double* partial, int blocks, hipStream_t s);
 
 // host: largest eigenvalue of a symmetric PSD n x n matrix (row-major float), in double
 double host_lambda_max(const float* S, int n);

@@ -140,7 +140,39 @@ inline unsigned grid_for(size_t n) {
     return (unsigned)g;
 }
 
+// Partial sums of  sum(Q * W) - 2 sum(W * B^T) + trace(C)  in double, one per workgroup (fixed
+// order inside a workgroup; the host adds the partials in order).  Q = W A (d x r), B is r x d.
+__global__ __launch_bounds__(256) void surrogate_partial_kernel(int d, int r, const float* __restrict__ Q,
+                                                                const float* __restrict__ W,
+                                                                const float* __restrict__ B,
+                                                                const float* __restrict__ Cagg,
+                                                                double* __restrict__ partial) {
+    __shared__ double red[256];
+    const size_t n = (size_t)d * r;
+    double acc = 0.0;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+        const int i = (int)(e / r), j = (int)(e % r);
+        const double w = W[e];
+        acc += w * ((double)Q[e] - 2.0 * (double)B[(size_t)j * d + i]);
+    }
+    if (Cagg != nullptr)
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < d; i += gridDim.x * 256) acc += (double)Cagg[(size_t)i * d + i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
 }  // namespace
+
+int launch_surrogate_partials(int d, int r, const float* Q, const float* W, const float* B, const float* Cagg,
+                              double* partial, int blocks, hipStream_t s) {
+    hipLaunchKernelGGL(surrogate_partial_kernel, dim3(blocks), dim3(256), 0, s, d, r, Q, W, B, Cagg, partial);
+    return hipGetLastError() == hipSuccess ? ONMF_OK : ONMF_ERR_HIP;
+}
 
 int launch_fill_uniform(float* out, size_t n, uint64_t seed, hipStream_t s) {
     if (n == 0) return ONMF_OK;

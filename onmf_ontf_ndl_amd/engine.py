@@ -251,6 +251,17 @@ class Engine:
         _lib.check(rc, self.ctx, "onmf_fold_patches")
         return out, count
 
+    def surrogate_loss(self, W, A, B, Cagg=None):
+        """tr(W A W^T) - 2 tr(W B) + tr(C) (ising_reconstruction.py:133), a Python float."""
+        d, r = W.shape
+        if tuple(A.shape) != (r, r) or tuple(B.shape) != (r, d) or (Cagg is not None and tuple(Cagg.shape) != (d, d)):
+            raise ValueError("surrogate_loss: A must be (r,r), B (r,d), C (d,d)")
+        loss = C.c_double(0.0)
+        rc = self.lib.onmf_surrogate_loss(self.ctx, d, r, _ptr(W), _ptr(A), _ptr(B), _ptr(Cagg), C.byref(loss),
+                                          self.stream())
+        _lib.check(rc, self.ctx, "onmf_surrogate_loss")
+        return loss.value
+
     def rand(self, rows, cols, seed=None):
         out = self.empty(rows, cols)
         if seed is None:

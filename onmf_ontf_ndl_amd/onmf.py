@@ -24,7 +24,7 @@ import numpy as np
 from . import _lib
 from .engine import get_engine
 
-__all__ = ["Online_NMF", "update_code_within_radius", "sparse_code_update", "dict_update"]
+__all__ = ["Online_NMF", "update_code_within_radius", "sparse_code_update", "dict_update", "surrogate_loss"]
 
 DEBUG = False
 
@@ -250,3 +250,10 @@ def sparse_code_update(X, W, H0=None, alpha=0, sub_iter=10, stopping_diff=0.01, 
 def dict_update(W, A, B, device=None):
     eng = get_engine(device)
     return _out(eng.update_dict(eng.dev(W), eng.dev(A), eng.dev(B)), _is_torch(W))
+
+
+def surrogate_loss(W, A, B, C=None, device=None):
+    """tr(W A W^T) - 2 tr(W B) + tr(C): the convergence monitor that the reference's drivers compute
+    from the three aggregates after each round (ising_reconstruction.py:133, :164)."""
+    eng = get_engine(device)
+    return eng.surrogate_loss(eng.dev(W), eng.dev(A), eng.dev(B), None if C is None else eng.dev(C))

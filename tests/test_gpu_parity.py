@@ -220,6 +220,26 @@ def test_g6_full_code_third_aggregate(eng, orc):
         assert relerr(got, g[key]) < (TOL_W if key == "W" else TOL_AGG)
     loss = orc.surrogate_loss(W, *agg)
     assert abs(loss - g["loss"]) < 1e-3 * max(1.0, abs(g["loss"]))
+    # the device monitor on the same state (ising_reconstruction.py:133)
+    from onmf_ontf_ndl_amd.onmf import surrogate_loss
+    dev_loss = surrogate_loss(W, *agg)
+    # the three traces are each ~|C|-sized and cancel: tolerance relative to the largest of them
+    scale = max(1.0, abs(np.trace(agg[2])))
+    assert abs(dev_loss - loss) < 1e-5 * scale
+    assert abs(surrogate_loss(W, agg[0], agg[1]) - (loss - np.trace(agg[2]))) < 1e-5 * scale
+
+
+@pytest.mark.parametrize("d,r", [(1024, 256), (441, 25), (7, 3)])
+def test_surrogate_loss_matches_float64(eng, orc, d, r):
+    rs = np.random.RandomState(d + r)
+    W = rs.rand(d, r).astype(np.float32)
+    H = rs.rand(r, 50)
+    X = rs.rand(d, 50)
+    A, B, Cm = (H @ H.T / 50).astype(np.float32), (H @ X.T / 50).astype(np.float32), (X @ X.T / 50).astype(np.float32)
+    got = eng.surrogate_loss(eng.dev(W), eng.dev(A), eng.dev(B), eng.dev(Cm))
+    ref = orc.surrogate_loss(W.astype(np.float64), A.astype(np.float64), B.astype(np.float64), Cm.astype(np.float64))
+    scale = abs(np.trace(W.astype(np.float64) @ A @ W.T.astype(np.float64)))
+    assert abs(got - ref) < 2e-6 * scale
 
 
 def test_g7_beta_and_alpha(eng):
