@@ -166,6 +166,37 @@ int onmf_fold_patches(onmf_ctx* ctx, const float* R, int ldr, int h, int w, int 
 int onmf_surrogate_loss(onmf_ctx* ctx, int d, int r, const float* W, const float* A, const float* B,
                         const float* C, double* loss, void* stream);
 
+/*
+ * Patch source of network dictionary learning: Markov chains of motif embeddings into a graph and
+ * the k x k adjacency matrix each embedding induces (network_reconstruction_nx.py:280-329,
+ * get_patches_glauber / chd_gen_mx with iterations=1).
+ *   graph     CSR, device int32: row_ptr[n_nodes+1], nbr[row_ptr[n_nodes]] with every row sorted
+ *             ascending (an undirected graph stores both directions).
+ *   motif     device int32[k*k], row-major 0/1 adjacency of the rooted tree motif in depth-first
+ *             order (path_adj, :86-95), 1 <= k <= 64; for every i >= 1 the first 1 of column i must
+ *             lie in a row < i (find_parent, :100-106).
+ *   emb       device int32[n_chains*k], in/out: node that motif node q of chain c sits on.
+ *   chain_kind  ONMF_NDL_GLAUBER (glauber_gen_update, :136-173) or ONMF_NDL_PIVOT (Pivot_update,
+ *             :265-278 = RW_update :175-199 + tree_sample :108-134).
+ * Every chain advances `steps` times; the patch after step s of chain c is column c*steps + s of
+ * X (k*k x ldx, feature q*k + r = has_edge(emb[q], emb[r]), values 0/1).  n_chains = 1 is the
+ * reference's single sequential chain; more chains are independent replicas of it.
+ * Randomness is Philox4x32-10 keyed by `seed`, a pure function of (chain, step_offset + s, slot):
+ * a later call continues the same chains when it passes step_offset = steps already taken.
+ * (The reference draws from NumPy's global generator; its stream cannot be followed on the device.)
+ * onmf_ndl_init_embeddings: emb[c] = tree_sample(motif, pivots[c]); pivots == NULL draws each pivot
+ * uniformly (train_dict, :351-352).
+ */
+#define ONMF_NDL_GLAUBER 0
+#define ONMF_NDL_PIVOT 1
+int onmf_ndl_init_embeddings(onmf_ctx* ctx, int n_nodes, const int32_t* row_ptr, const int32_t* nbr,
+                             int k, const int32_t* motif, int n_chains, const int32_t* pivots,
+                             uint64_t seed, int32_t* emb, void* stream);
+int onmf_ndl_sample_patches(onmf_ctx* ctx, int n_nodes, const int32_t* row_ptr, const int32_t* nbr,
+                            int k, const int32_t* motif, int chain_kind, int n_chains, int steps,
+                            int32_t* emb, uint64_t seed, uint64_t step_offset, float* X, int ldx,
+                            void* stream);
+
 /* U[0,1) fill, the device stand-in for np.random.rand (src/onmf.py:190, :246). */
 int onmf_fill_uniform(onmf_ctx* ctx, float* out, size_t n, uint64_t seed, void* stream);
 

@@ -22,6 +22,8 @@ OPT_OVERLAP_DICT = 4
 OPT_SCREEN_STOP = 5
 OPT_DICT_KERNEL = 6
 OPT_PERSISTENT_SWEEPS = 7
+NDL_GLAUBER = 0
+NDL_PIVOT = 1
 
 _f = C.c_void_p          # device float*
 _ctx = C.c_void_p
@@ -57,6 +59,11 @@ SIGNATURES = {
                                     C.c_int, _f, _f, C.c_void_p]),
     "onmf_surrogate_loss": (C.c_int, [_ctx, C.c_int, C.c_int, _f, _f, _f, _f, C.POINTER(C.c_double),
                                       C.c_void_p]),
+    "onmf_ndl_init_embeddings": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                           C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "onmf_ndl_sample_patches": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                          C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, _f, C.c_int,
+                                          C.c_void_p]),
     "onmf_fill_uniform": (C.c_int, [_ctx, _f, C.c_size_t, C.c_uint64, C.c_void_p]),
     "onmf_host_lambda_max": (C.c_double, [C.c_void_p, C.c_int]),
     "onmf_set_option": (C.c_int, [_ctx, C.c_int, C.c_int]),

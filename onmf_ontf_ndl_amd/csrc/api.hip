@@ -779,6 +779,43 @@ int onmf_surrogate_loss(onmf_ctx* c, int d, int r, const float* W, const float* 
     return ONMF_OK;
 }
 
+static int ndl_args(onmf_ctx* c, const char* what, int n_nodes, const int32_t* row_ptr, const int32_t* nbr, int k,
+                    const int32_t* motif, int n_chains, const int32_t* emb) {
+    if (n_nodes <= 0 || !row_ptr || !nbr || !motif || !emb || n_chains <= 0)
+        return onmf_fail(c, ONMF_ERR_ARG, "%s: bad arguments", what);
+    if (k < 1 || k > 64) return onmf_fail(c, ONMF_ERR_ARG, "%s: motif size k=%d is not in 1..64", what, k);
+    return ONMF_OK;
+}
+
+int onmf_ndl_init_embeddings(onmf_ctx* c, int n_nodes, const int32_t* row_ptr, const int32_t* nbr, int k,
+                             const int32_t* motif, int n_chains, const int32_t* pivots, uint64_t seed,
+                             int32_t* emb, void* stream) {
+    if (!c) return ONMF_ERR_ARG;
+    ONMF_TRY(ndl_args(c, "ndl_init_embeddings", n_nodes, row_ptr, nbr, k, motif, n_chains, emb));
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (launch_ndl_chains(n_nodes, row_ptr, nbr, k, motif, 2, n_chains, 0, emb, pivots, seed, 0, nullptr, 0,
+                          (hipStream_t)stream) != ONMF_OK)
+        return onmf_fail(c, ONMF_ERR_HIP, "ndl_init_embeddings: launch failed");
+    return ONMF_OK;
+}
+
+int onmf_ndl_sample_patches(onmf_ctx* c, int n_nodes, const int32_t* row_ptr, const int32_t* nbr, int k,
+                            const int32_t* motif, int chain_kind, int n_chains, int steps, int32_t* emb,
+                            uint64_t seed, uint64_t step_offset, float* X, int ldx, void* stream) {
+    if (!c) return ONMF_ERR_ARG;
+    ONMF_TRY(ndl_args(c, "ndl_sample_patches", n_nodes, row_ptr, nbr, k, motif, n_chains, emb));
+    if (chain_kind != ONMF_NDL_GLAUBER && chain_kind != ONMF_NDL_PIVOT)
+        return onmf_fail(c, ONMF_ERR_ARG, "ndl_sample_patches: unknown chain kind %d", chain_kind);
+    if (steps <= 0 || !X || (long long)n_chains * steps > ldx)
+        return onmf_fail(c, ONMF_ERR_ARG, "ndl_sample_patches: %d chains x %d steps do not fit ldx=%d", n_chains, steps,
+                         ldx);
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (launch_ndl_chains(n_nodes, row_ptr, nbr, k, motif, chain_kind, n_chains, steps, emb, nullptr, seed, step_offset,
+                          X, ldx, (hipStream_t)stream) != ONMF_OK)
+        return onmf_fail(c, ONMF_ERR_HIP, "ndl_sample_patches: launch failed");
+    return ONMF_OK;
+}
+
 int onmf_fill_uniform(onmf_ctx* c, float* out, size_t n, uint64_t seed, void* stream) {
     if (!c) return ONMF_ERR_ARG;
     if (!out && n) return onmf_fail(c, ONMF_ERR_ARG, "fill_uniform: null output");

@@ -133,6 +133,11 @@ int launch_patch_extract(const float* img, int h, int w, int ch, int k, const in
 int launch_patch_fold(const float* R, int ldr, int h, int w, int ch, int k, int grid_rows, int grid_cols, int stride,
                       float* out, float* count, hipStream_t s);
 
+// Motif-sampling chains (ndl.hip): mode 0 Glauber, 1 pivot, 2 initial embedding from pivots.
+int launch_ndl_chains(int n, const int* row_ptr, const int* nbr, int k, const int* motif, int mode, int n_chains,
+                      int steps, int* emb, const int* pivots, uint64_t seed, uint64_t step0, float* X, int ldx,
+                      hipStream_t s);
+
 // Stopping-test screen: state layout and kernels.
 constexpr int SCREEN_MAX_SWEEPS = 64;
 constexpr int SCREEN_REPL = 8;       // replicas of the sweep kernel's accumulators (atomic contention)

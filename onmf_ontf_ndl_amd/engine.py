@@ -262,6 +262,42 @@ class Engine:
         _lib.check(rc, self.ctx, "onmf_surrogate_loss")
         return loss.value
 
+    # ------------------------------------------------------------------ network patches
+    def ndl_graph(self, row_ptr, nbr):
+        """CSR graph (sorted rows) on this GPU, as the chain kernels take it."""
+        i32 = self.torch.int32
+        return {"n": int(len(row_ptr) - 1), "row_ptr": self.dev(row_ptr, i32), "nbr": self.dev(nbr, i32)}
+
+    def ndl_init_embeddings(self, graph, motif, n_chains, pivots=None, seed=0):
+        """tree_sample from one pivot per chain (network_reconstruction_nx.py:108-134, :351-352)."""
+        i32 = self.torch.int32
+        motif = self.dev(motif, i32)
+        k = motif.shape[0]
+        piv = None if pivots is None else self.dev(pivots, i32)
+        emb = self.torch.zeros(n_chains, k, dtype=i32, device=self.device)
+        rc = self.lib.onmf_ndl_init_embeddings(self.ctx, graph["n"], _ptr(graph["row_ptr"]), _ptr(graph["nbr"]), k,
+                                               _ptr(motif), int(n_chains), _ptr(piv), C.c_uint64(seed), _ptr(emb),
+                                               self.stream())
+        _lib.check(rc, self.ctx, "onmf_ndl_init_embeddings")
+        return emb
+
+    def ndl_sample_patches(self, graph, motif, emb, steps, glauber=True, seed=0, step_offset=0):
+        """Advance every chain ``steps`` times; returns X (k*k x n_chains*steps) and updates ``emb`` in place
+        (network_reconstruction_nx.py:315-329)."""
+        i32 = self.torch.int32
+        motif = self.dev(motif, i32)
+        k = motif.shape[0]
+        if emb.dtype != i32 or emb.dim() != 2 or emb.shape[1] != k or not emb.is_contiguous():
+            raise ValueError("emb must be a contiguous int32 (n_chains, %d) tensor" % k)
+        n_chains = emb.shape[0]
+        X = self.empty(k * k, n_chains * int(steps))
+        rc = self.lib.onmf_ndl_sample_patches(self.ctx, graph["n"], _ptr(graph["row_ptr"]), _ptr(graph["nbr"]), k,
+                                              _ptr(motif), _lib.NDL_GLAUBER if glauber else _lib.NDL_PIVOT, n_chains,
+                                              int(steps), _ptr(emb), C.c_uint64(seed), C.c_uint64(step_offset),
+                                              _ptr(X), X.stride(0), self.stream())
+        _lib.check(rc, self.ctx, "onmf_ndl_sample_patches")
+        return X
+
     def rand(self, rows, cols, seed=None):
         out = self.empty(rows, cols)
         if seed is None:
