@@ -64,33 +64,52 @@ int onmf_reserve_pinned(onmf_ctx* c, size_t bytes) {
 // largest eigenvalue of a symmetric PSD matrix: Lanczos with full re-orthogonalisation, the
 // tridiagonal's top eigenvalue by Sturm-sequence bisection; all in double.
 // ---------------------------------------------------------------------------------------------
-static double tridiag_top(const std::vector<double>& a, const std::vector<double>& b, int m) {
+// number of eigenvalues of the symmetric tridiagonal (a, b) of order m that are < x (Sturm count)
+static int tridiag_below(const std::vector<double>& a, const std::vector<double>& b, int m, double x) {
+    int cnt = 0;
+    double q = a[0] - x;
+    if (q < 0) ++cnt;
+    for (int i = 1; i < m; ++i) {
+        if (q == 0.0) q = 1e-300;
+        q = a[i] - x - b[i - 1] * b[i - 1] / q;
+        if (q < 0) ++cnt;
+    }
+    return cnt;
+}
+
+// top eigenvalue by bisection; `floor` is a known lower bound of it (or -inf)
+static double tridiag_top(const std::vector<double>& a, const std::vector<double>& b, int m, double floor) {
+    if (m == 1) return a[0];
     double lo = std::numeric_limits<double>::infinity(), hi = -lo;
     for (int i = 0; i < m; ++i) {
         const double off = (i > 0 ? std::fabs(b[i - 1]) : 0.0) + (i + 1 < m ? std::fabs(b[i]) : 0.0);
         lo = std::min(lo, a[i] - off);
         hi = std::max(hi, a[i] + off);
     }
-    if (m == 1) return a[0];
-    auto below = [&](double x) {   // number of eigenvalues < x
-        int cnt = 0;
-        double q = a[0] - x;
-        if (q < 0) ++cnt;
-        for (int i = 1; i < m; ++i) {
-            if (q == 0.0) q = 1e-300;
-            q = a[i] - x - b[i - 1] * b[i - 1] / q;
-            if (q < 0) ++cnt;
-        }
-        return cnt;
-    };
+    if (floor > lo && floor <= hi) lo = floor;
     for (int it = 0; it < 200 && hi - lo > 1e-16 * std::max(std::fabs(hi), std::fabs(lo)); ++it) {
         const double mid = 0.5 * (lo + hi);
-        if (below(mid) >= m) hi = mid; else lo = mid;
+        if (tridiag_below(a, b, m, mid) >= m) hi = mid; else lo = mid;
     }
     return 0.5 * (lo + hi);
 }
 
+static inline double dot4(const double* x, const double* y, int n) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int i = 0;
+    for (; i + 3 < n; i += 4) {
+        s0 += x[i] * y[i];
+        s1 += x[i + 1] * y[i + 1];
+        s2 += x[i + 2] * y[i + 2];
+        s3 += x[i + 3] * y[i + 3];
+    }
+    for (; i < n; ++i) s0 += x[i] * y[i];
+    return (s0 + s1) + (s2 + s3);
+}
+
 // `enough` > 0: return as soon as a Ritz value (always a lower bound of the top eigenvalue) reaches it.
+// The top Ritz value only grows from step to step; it is evaluated at every step while the basis is
+// small and every fourth step after that (its bisection costs as much as the step itself).
 static double lambda_max_impl(const float* S, int n, double enough) {
     if (n <= 0) return 0.0;
     if (n == 1) return (double)S[0];
@@ -98,7 +117,8 @@ static double lambda_max_impl(const float* S, int n, double enough) {
     for (size_t i = 0; i < (size_t)n * n; ++i) fro += (double)S[i] * S[i];
     if (!(fro > 0.0)) return (fro == 0.0) ? 0.0 : std::numeric_limits<double>::quiet_NaN();
     const int mmax = n;
-    std::vector<double> V((size_t)(mmax + 1) * n), w(n), al, be;
+    std::vector<double> Sd((size_t)n * n), V((size_t)(mmax + 1) * n), w(n), al, be;
+    for (size_t i = 0; i < (size_t)n * n; ++i) Sd[i] = (double)S[i];
     // deterministic start vector with a component along every coordinate
     double nv = 0.0;
     for (int i = 0; i < n; ++i) {
@@ -108,41 +128,54 @@ static double lambda_max_impl(const float* S, int n, double enough) {
     nv = std::sqrt(nv);
     for (int i = 0; i < n; ++i) V[i] /= nv;
     double theta = 0.0, prev = -1.0;
+    bool theta_current = false;
     int calm = 0;
     for (int j = 0; j < mmax; ++j) {
         const double* vj = &V[(size_t)j * n];
-        for (int i = 0; i < n; ++i) {
-            const float* row = S + (size_t)i * n;
-            double acc = 0.0;
-            for (int k = 0; k < n; ++k) acc += (double)row[k] * vj[k];
-            w[i] = acc;
-        }
-        double a = 0.0;
-        for (int i = 0; i < n; ++i) a += w[i] * vj[i];
-        al.push_back(a);
+        for (int i = 0; i < n; ++i) w[i] = dot4(&Sd[(size_t)i * n], vj, n);
+        al.push_back(dot4(w.data(), vj, n));
         for (int pass = 0; pass < 2; ++pass) {
             for (int l = 0; l <= j; ++l) {
                 const double* vl = &V[(size_t)l * n];
-                double c = 0.0;
-                for (int i = 0; i < n; ++i) c += w[i] * vl[i];
+                const double c = dot4(w.data(), vl, n);
                 for (int i = 0; i < n; ++i) w[i] -= c * vl[i];
             }
         }
-        double bn = 0.0;
-        for (int i = 0; i < n; ++i) bn += w[i] * w[i];
-        bn = std::sqrt(bn);
-        theta = tridiag_top(al, be, j + 1);
-        if (enough > 0.0 && theta >= enough) break;
-        if (bn <= 1e-14 * std::sqrt(fro) || j + 1 == mmax) break;
-        if (n > 48) {       // small matrices run the full n steps (exact); larger ones stop on stagnation
-            if (std::fabs(theta - prev) <= 4e-16 * std::fabs(theta)) ++calm; else calm = 0;
-            if (calm >= 6 && j >= 24) break;
+        const double bn = std::sqrt(dot4(w.data(), w.data(), n));
+        const int m = j + 1;
+        const bool last = bn <= 1e-14 * std::sqrt(fro) || m == mmax;
+        theta_current = false;
+        if (enough > 0.0 && tridiag_below(al, be, m, enough) < m) {
+            // a Ritz value >= enough exists: report it
+            return tridiag_top(al, be, m, enough);
         }
-        prev = theta;
+        if (last) {
+            theta = tridiag_top(al, be, m, prev > 0.0 ? prev : -std::numeric_limits<double>::infinity());
+            theta_current = true;
+            break;
+        }
+        // Small matrices run all n steps (exact) and need the Ritz value only at the end.  Larger ones
+        // stop once it stagnates: from step 16 on, every fourth step, first asking with one Sturm count
+        // whether it has moved at all (the bisection costs as much as several steps).
+        if (n > 48 && m >= 16 && (m & 3) == 0) {
+            const bool moved = prev <= 0.0 || tridiag_below(al, be, m, prev * (1.0 + 1e-14)) < m;
+            if (moved) {
+                theta = tridiag_top(al, be, m, prev > 0.0 ? prev : -std::numeric_limits<double>::infinity());
+                calm = 0;
+                prev = theta;
+            } else {
+                theta = prev;
+                if (++calm >= 2 && m >= 24) {
+                    theta_current = true;
+                    break;
+                }
+            }
+        }
         be.push_back(bn);
         double* vn = &V[(size_t)(j + 1) * n];
         for (int i = 0; i < n; ++i) vn[i] = w[i] / bn;
     }
+    if (!theta_current) theta = tridiag_top(al, be, (int)al.size(), prev);
     return theta;
 }
 

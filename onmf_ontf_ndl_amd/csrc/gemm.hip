@@ -271,19 +271,32 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmParams p) {
     }
 }
 
+// Sum of the split-K slabs with the  alpha * sum + beta * Cin  epilogue.  64 outputs per workgroup,
+// four threads per output: thread group g adds slabs g, g+4, g+8, ... in order, the four partial sums
+// are added in order - a fixed summation order whatever the grid, so results are reproducible, and a
+// few outputs with many slabs (the small Gram matrices) still spread over the chip.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab,
                                                              int splits, int M, int N, float alpha,
                                                              float beta, const float* Cin,
                                                              float* C, int ldc) {
+    __shared__ float part[4][64];
     const size_t mn = (size_t)M * N;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < mn;
-         i += (size_t)gridDim.x * blockDim.x) {
+    const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
+    for (size_t base = (size_t)blockIdx.x * 64; base < mn; base += (size_t)gridDim.x * 64) {
+        const size_t i = base + o;
         float s = 0.f;
-        for (int z = 0; z < splits; ++z) s += slab[(size_t)z * mn + i];
-        const int row = (int)(i / N), col = (int)(i % N);
-        float v = alpha * s;
-        if (beta != 0.f) v += beta * Cin[(size_t)row * ldc + col];
-        C[(size_t)row * ldc + col] = v;
+        if (i < mn)
+            for (int z = g; z < splits; z += 4) s += slab[(size_t)z * mn + i];
+        part[g][o] = s;
+        __syncthreads();
+        if (g == 0 && i < mn) {
+            const float t = ((part[0][o] + part[1][o]) + part[2][o]) + part[3][o];
+            const int row = (int)(i / N), col = (int)(i % N);
+            float v = alpha * t;
+            if (beta != 0.f) v += beta * Cin[(size_t)row * ldc + col];
+            C[(size_t)row * ldc + col] = v;
+        }
+        __syncthreads();
     }
 }
 
@@ -346,8 +359,8 @@ int launch_gemm(onmf_ctx* c, bool a_km, bool b_kn, int M, int N, int K, const fl
     if (rc != ONMF_OK) return rc;
     if (splits > 1) {
         const size_t mn = (size_t)M * N;
-        int blocks = (int)((mn + 255) / 256);
-        if (blocks > 2048) blocks = 2048;
+        int blocks = (int)((mn + 63) / 64);
+        if (blocks > 4096) blocks = 4096;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, p.slab, splits, M, N,
                            alpha, beta, Cin, C, ldc);
         HIP_TRY(c, hipGetLastError());
