@@ -284,8 +284,11 @@ static bool keep_sweeping(double dist, double tol) { return dist > tol; }
 // With ub_old > 0 (a rigorous upper bound of sigma_max(Hold)) and tol > 0 the cheap half is tried
 // first: only the Gram of the difference is formed, and the Lanczos run on it stops as soon as a
 // Ritz value (a lower bound of its top eigenvalue) proves dist > tol; *dist is then that bound.
+// *sigma_new_ub (optional) receives an upper bound of sigma_max(Hnew) when both halves ran
+// (sigma_max(Hold) + sigma_max(Hnew - Hold), widened for the fp32 rounding of the Grams), else -1.
 static int exact_dist(onmf_ctx* c, int r, int b, const float* Hnew, const float* Hold, hipStream_t s,
-                      double* dist, double ub_old = -1.0, double tol = -1.0) {
+                      double* dist, double ub_old = -1.0, double tol = -1.0, double* sigma_new_ub = nullptr) {
+    if (sigma_new_ub) *sigma_new_ub = -1.0;
     const size_t rb = (size_t)r * b;
     const size_t rr = (size_t)r * r;
     ONMF_TRY(onmf_reserve(c, c->dbuf, rb * sizeof(float), "code difference"));
@@ -313,6 +316,7 @@ static int exact_dist(onmf_ctx* c, int r, int b, const float* Hnew, const float*
     const double l1 = host_lambda_max(hg, r);
     const double l0 = host_lambda_max(hg + rr, r);
     *dist = std::sqrt(std::max(l1, 0.0)) / std::sqrt(std::max(l0, 0.0));
+    if (sigma_new_ub && l0 > 0.0 && l1 >= 0.0) *sigma_new_ub = (std::sqrt(l0) + std::sqrt(l1)) * (1.0 + 1e-5);
     return ONMF_OK;
 }
 
@@ -389,7 +393,7 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
     const double nan = std::numeric_limits<double>::quiet_NaN();
     int done = 0;
 
-    const bool screened = !exact_cd && tol > 0.0 && !c->exact_stop && c->screen_stop &&
+    const bool screened = !exact_cd && tol >= 0.0 && !c->exact_stop && c->screen_stop &&
                           c->sweep_kernel != 1 && sweep_tile_covers(r, b) &&
                           sub_iter <= SCREEN_MAX_SWEEPS && keep_sweeping(1.0, tol);
     if (screened) {
@@ -470,11 +474,17 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
                 }
                 double dist = nan;                        // bounds straddle tol: evaluate in full
                 undecided = true;
-                ONMF_TRY(exact_dist(c, r, b, buf[(i + 1) % 3], buf[i % 3], s, &dist, (double)rec[4 * i + 3], tol));
+                // With several sweeps to go, both halves of the test are evaluated even where the cheap
+                // one would do: the exact sigma_max(H) they give makes the bounds of the sweeps that
+                // follow tight (H moves little from here on), which saves their host round trips.
+                const bool seed_bound = i + 2 < sub_iter;
+                double ub_next = -1.0;
+                ONMF_TRY(exact_dist(c, r, b, buf[(i + 1) % 3], buf[i % 3], s, &dist,
+                                    seed_bound ? -1.0 : (double)rec[4 * i + 3], tol, &ub_next));
                 if (dist_trace) dist_trace[i] = (float)dist;
                 if (!keep_sweeping(dist, tol)) { stop = true; break; }
                 if (i + 1 < sub_iter) {
-                    ONMF_TRY(launch_screen_clear_flag(c, base, i + 1, s));
+                    ONMF_TRY(launch_screen_clear_flag(c, base, i + 1, s, (float)ub_next));
                     // the probes were not good enough to decide: one power step on this very move
                     ONMF_TRY(launch_screen_refresh(c, base, r, b, buf[(i + 1) % 3], buf[i % 3], s));
                 }

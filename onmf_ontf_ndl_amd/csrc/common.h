@@ -248,8 +248,9 @@ int launch_screen_init(onmf_ctx* c, float* base, int r, hipStream_t s);
 // the verdicts that no sweep of the launch evaluated: sweeps k_from .. k_last, in order
 int launch_screen_final(onmf_ctx* c, float* base, int k_from, int k_last, float tol, float rank_cap,
                         hipStream_t s);
-// reopen the loop after the host settled sweep k - 1: flag = 0, no bound known for sweep k
-int launch_screen_clear_flag(onmf_ctx* c, float* base, int k, hipStream_t s);
+// reopen the loop after the host settled sweep k - 1: flag = 0; ub = an upper bound of
+// sigma_max(H before sweep k) if the host knows one, else -1
+int launch_screen_clear_flag(onmf_ctx* c, float* base, int k, hipStream_t s, float ub = -1.0f);
 // device-side: copy hb[done % 3] to dst, if that is another buffer, where done comes from the records
 int launch_screen_finalize(onmf_ctx* c, const float* base, int sub_iter, float* const* hb, float* dst,
                            size_t n, hipStream_t s);

@@ -43,10 +43,18 @@ __global__ __launch_bounds__(256) void screen_init_kernel(float* base, int r, in
     if (tid == 0) base[ScreenLayout::AVEC] = 1.0f;
 }
 
-__global__ void screen_clear_flag_kernel(float* base, int k) {
+// Reopen the loop at sweep k after the host settled sweep k - 1.  The launch that was stopped had
+// already run sweep k ahead of that verdict: its sums and its count of finished workgroups are
+// stale and sweep k is about to add its own again, so the accumulator sets from k on start over.
+__global__ void screen_clear_flag_kernel(float* base, int k, float ub) {
+    for (int j = k; j < SCREEN_MAX_SWEEPS && j < k + 2; ++j) {
+        for (int e = threadIdx.x; e < ScreenLayout::SETSZ; e += blockDim.x)
+            base[ScreenLayout::SETS + j * ScreenLayout::SETSZ + e] = 0.f;
+        if (threadIdx.x == 0) reinterpret_cast<int*>(base)[ScreenLayout::CNT + j] = 0;
+    }
     if (threadIdx.x == 0) {
         reinterpret_cast<int*>(base)[ScreenLayout::FLAG] = 0;
-        base[ScreenLayout::UBH + k] = -1.0f;
+        base[ScreenLayout::UBH + k] = ub;
     }
 }
 
@@ -324,8 +332,8 @@ int launch_screen_refresh(onmf_ctx* c, float* base, int r, int b, const float* H
     return ONMF_OK;
 }
 
-int launch_screen_clear_flag(onmf_ctx* c, float* base, int k, hipStream_t s) {
-    hipLaunchKernelGGL(screen_clear_flag_kernel, dim3(1), dim3(64), 0, s, base, k);
+int launch_screen_clear_flag(onmf_ctx* c, float* base, int k, hipStream_t s, float ub) {
+    hipLaunchKernelGGL(screen_clear_flag_kernel, dim3(1), dim3(64), 0, s, base, k, ub);
     HIP_TRY(c, hipGetLastError());
     return ONMF_OK;
 }

@@ -59,6 +59,32 @@ def test_screen_agrees_with_full_test(eng, d, r, b):
         assert torch.equal(He2, Hs2)
 
 
+def test_bounds_stay_valid_after_the_host_settles_a_sweep(eng):
+    """A long solve whose tolerance sits just under the dist of a middle sweep: the bounds cannot
+    decide there, the host does and relaunches.  The sweep that had run ahead of that verdict runs
+    again, and every value reported afterwards must still bound the exact dist from below."""
+    import torch
+    g = torch.Generator(device=eng.device).manual_seed(321)
+    d, r, b = 96, 48, 2500
+    X = torch.rand(d, b, device=eng.device, generator=g)
+    W = torch.rand(d, r, device=eng.device, generator=g)
+    W = W / torch.clamp(torch.linalg.norm(W, dim=0), min=1.0)
+    H0 = torch.rand(r, b, device=eng.device, generator=g)
+    eng.set_option(EXACT, 1)
+    _, _, de = eng.sparse_code(X, W, H0=H0, sub_iter=30, stopping_diff=0.0)
+    eng.set_option(EXACT, 0)
+    assert len(de) == 30
+    for k in (6, 14, 22):
+        tol = float(min(de[:k + 1]) * 0.98)
+        eng.set_option(EXACT, 1)
+        He, se, dex = eng.sparse_code(X, W, H0=H0, sub_iter=30, stopping_diff=tol)
+        eng.set_option(EXACT, 0)
+        Hs, ss, ds = eng.sparse_code(X, W, H0=H0, sub_iter=30, stopping_diff=tol)
+        assert ss == se and torch.equal(He, Hs)
+        for i in range(ss - 1):
+            assert ds[i] <= dex[i] * (1 + 1e-3), (k, i, ds[i], dex[i])
+
+
 def test_screen_early_stop_and_zero_code(eng):
     import torch
     g = torch.Generator(device=eng.device).manual_seed(5)
