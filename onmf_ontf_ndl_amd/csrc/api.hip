@@ -416,18 +416,24 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
         while (start < sub_iter) {
             const ScreenDev sc = {base, start, (float)tol, (float)rank_cap, 200000000LL /* 2 s */};
             int i = start;
+            // When the probes are due for a power step, it is taken on the move of the SECOND sweep (the
+            // first one is the jump away from the random start; the later moves resemble each other
+            // and the second), so the launch is cut after that sweep.
+            const int refresh_after = sub_iter >= 3 ? 1 : 0;
             while (i < sub_iter) {
-                // the first sweep of the solve stands alone when a probe power step follows it
                 int count = persistent ? sub_iter - i : 1;
-                if (i == 0 && refresh_probes) count = 1;
+                const bool cut = start == 0 && refresh_probes && i <= refresh_after;
+                if (cut) count = std::min(count, refresh_after + 1 - i);
                 int groups = 0;
                 ONMF_TRY(profile_mark(c, s));
                 ONMF_TRY(launch_sweep(c, r, b, Gm, Cm, buf, alpha, 0, i, count, (double*)c->stats.p, &groups, s, &sc));
                 ONMF_TRY(profile_mark(c, s));
-                // a power step of the probe subspace on the first sweep's move, when the probes kept
-                // from the previous solve left little margin (or there are none yet)
-                if (i == 0 && refresh_probes) ONMF_TRY(launch_screen_refresh(c, base, r, b, buf[1], buf[0], s));
                 i += count;
+                if (cut && i == refresh_after + 1) {
+                    ONMF_TRY(launch_screen_refresh(c, base, r, b, buf[i % 3], buf[(i - 1) % 3], s));
+                    // and a tight bound of sigma_max of the code the next sweep starts from (>= 0 now)
+                    if (i < sub_iter) ONMF_TRY(launch_screen_cw(c, base, r, b, buf[i % 3], i, s));
+                }
             }
             // a sweep evaluates the test of the one two sweeps back: the last two are still open
             ONMF_TRY(launch_screen_final(c, base, std::max(start, sub_iter - 2), sub_iter - 1, (float)tol,

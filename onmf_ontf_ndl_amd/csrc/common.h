@@ -144,7 +144,8 @@ constexpr int SCREEN_REPL = 8;       // replicas of the sweep kernel's accumulat
 constexpr int SCREEN_ZREPL = 4;      // replicas of the power-step accumulator
 struct ScreenLayout {           // offsets in floats into ctx->screen
     static constexpr int UBLK = 0;                                 // 16 * 256: probe blocks
-    static constexpr int ZACC = 4096;                              // ZREPL x 256 x 16
+    static constexpr int CWV = 4096;                               // 256: positive vector of the Collatz-Wielandt bound
+    static constexpr int ZACC = CWV + 256;                         // ZREPL x 256 x 16
     // one accumulator set per sweep of the solve (never reused: no clearing races)
     static constexpr int SETS = ZACC + SCREEN_ZREPL * 4096;
     static constexpr int SET_P2 = 0;                               // REPL x 16 probe energies
@@ -155,9 +156,11 @@ struct ScreenLayout {           // offsets in floats into ctx->screen
     static constexpr int FLAG = UBH + SCREEN_MAX_SWEEPS + 1;       // int: 0 = keep sweeping
     static constexpr int AVEC = FLAG + 1;          // 16: last Ritz coefficient vector (warm start)
     static constexpr int REC = AVEC + 16;          // SCREEN_MAX_SWEEPS x 4 floats
-    static constexpr int TOTAL = REC + 4 * SCREEN_MAX_SWEEPS;
+    static constexpr int CWY = REC + 4 * SCREEN_MAX_SWEEPS;        // 256 doubles: H H^T v
+    static constexpr int TOTAL = CWY + 512;
 };
-static_assert(ScreenLayout::SETS % 2 == 0 && ScreenLayout::SETSZ % 2 == 0 && ScreenLayout::SET_SUMS % 2 == 0,
+static_assert(ScreenLayout::SETS % 2 == 0 && ScreenLayout::SETSZ % 2 == 0 && ScreenLayout::SET_SUMS % 2 == 0 &&
+                  ScreenLayout::CWY % 2 == 0,
               "double alignment");
 constexpr int SCREEN_FLAG_TIMEOUT = 4;     // a workgroup gave up waiting for the others
 
@@ -226,6 +229,11 @@ __device__ __forceinline__ int screen_eval_wave(float* base, int j, float& ub, f
     if (lane == 0) {
         float lower, upper, ubh;
         verdict = screen_verdict(e, dsum, hsum, ub, tol, rank_cap, lower, upper, ubh, ubn);
+        // a bound for the next sweep that was put there before the launch (Collatz-Wielandt, or the
+        // host's exact value) stands if it is the tighter one; every workgroup reads the same value
+        // or the minimum already taken with it, so all arrive at the same number
+        const float seeded = base[ScreenLayout::UBH + j + 1];
+        if (seeded > 0.f && seeded < ubn) ubn = seeded;
         if (record) {
             float* rec = base + ScreenLayout::REC + 4 * j;
             rec[0] = lower;
@@ -257,6 +265,9 @@ int launch_screen_finalize(onmf_ctx* c, const float* base, int sub_iter, float* 
 // one power step of the probe subspace on a sample of columns, then the probe update
 int launch_screen_refresh(onmf_ctx* c, float* base, int r, int b, const float* Hnew, const float* Hold,
                           hipStream_t s);
+// Collatz-Wielandt upper bound of sigma_max(H) for an entrywise nonnegative H = the code before sweep k:
+// stored as that sweep's bound, and one power step of the vector it uses
+int launch_screen_cw(onmf_ctx* c, float* base, int r, int b, const float* H, int k, hipStream_t s);
 
 int launch_dict_pass(onmf_ctx* c, int d, int r, const float* Win, const float* A, const float* B,
                      float* Wout, hipStream_t s);

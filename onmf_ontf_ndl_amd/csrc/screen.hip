@@ -41,6 +41,7 @@ __global__ __launch_bounds__(256) void screen_init_kernel(float* base, int r, in
             base[ScreenLayout::UBLK + K * 256 + blk_off(p, j)] = scale * hash_unit(tid * 16 + p + 1);
     }
     if (tid == 0) base[ScreenLayout::AVEC] = 1.0f;
+    if (!keep_probes) base[ScreenLayout::CWV + tid] = 1.0f;
 }
 
 // Reopen the loop at sweep k after the host settled sweep k - 1.  The launch that was stopped had
@@ -289,7 +290,83 @@ __global__ __launch_bounds__(256) void screen_probe_update_kernel(float* base, i
     }
 }
 
+// Collatz-Wielandt: for an entrywise nonnegative matrix M = H H^T and a positive vector v,
+// lambda_max(M) <= max_k (M v)_k / v_k - a rigorous upper bound of sigma_max(H)^2 that is tight when v
+// is close to the dominant eigenvector, which changes little from one solve to the next.
+// y = H (H^T v): pass 1, thread = column: t_c = v . H[:, c] (coalesced); pass 2, thread = row: the
+// workgroup's 256 columns of that row times t (contiguous per thread, served by the caches pass 1
+// filled), one double atomic per row and workgroup.
+__global__ __launch_bounds__(256) void screen_cw_kernel(int r, int b, const float* __restrict__ H, float* base) {
+    __shared__ float vs[256];
+    __shared__ float ts[256];
+    const int tid = threadIdx.x;
+    vs[tid] = tid < r ? base[ScreenLayout::CWV + tid] : 0.f;
+    __syncthreads();
+    const int c0 = blockIdx.x * 256;
+    const int c = c0 + tid;
+    float t = 0.f;
+    if (c < b)
+        for (int k = 0; k < r; ++k) t = fmaf(vs[k], H[(size_t)k * b + c], t);
+    ts[tid] = t;
+    __syncthreads();
+    if (tid < r) {
+        const float* row = H + (size_t)tid * b + c0;
+        const int n = min(256, b - c0);
+        float y0 = 0.f, y1 = 0.f, y2 = 0.f, y3 = 0.f;
+        int i = 0;
+        if ((((uintptr_t)row) & 15) == 0) {
+            for (; i + 3 < n; i += 4) {
+                const float4 h = *reinterpret_cast<const float4*>(row + i);
+                y0 = fmaf(h.x, ts[i], y0);
+                y1 = fmaf(h.y, ts[i + 1], y1);
+                y2 = fmaf(h.z, ts[i + 2], y2);
+                y3 = fmaf(h.w, ts[i + 3], y3);
+            }
+        }
+        for (; i < n; ++i) y0 = fmaf(row[i], ts[i], y0);
+        atomicAdd(reinterpret_cast<double*>(base + ScreenLayout::CWY) + tid, (double)((y0 + y1) + (y2 + y3)));
+    }
+}
+
+__global__ __launch_bounds__(256) void screen_cw_finish_kernel(int r, float* base, int k) {
+    __shared__ float red[256];
+    const int tid = threadIdx.x;
+    double* yp = reinterpret_cast<double*>(base + ScreenLayout::CWY);
+    const double y = tid < r ? yp[tid] : 0.0;
+    const float v = tid < r ? base[ScreenLayout::CWV + tid] : 1.f;
+    red[tid] = tid < r ? (float)(y / (double)v) * (1.0f + 1e-6f) : 0.f;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) red[tid] = fmaxf(red[tid], red[tid + off]);
+        __syncthreads();
+    }
+    const float lam = red[0];
+    __syncthreads();
+    red[tid] = (float)y;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) red[tid] = fmaxf(red[tid], red[tid + off]);
+        __syncthreads();
+    }
+    const float ymax = red[0];
+    if (tid < r) {
+        yp[tid] = 0.0;
+        // the power step; kept strictly positive (rows of H that are all zero would zero it)
+        if (ymax > 0.f && ymax < 3.0e38f) base[ScreenLayout::CWV + tid] = fmaxf((float)y / ymax, 1e-3f);
+    }
+    // (1 + 1e-4 on the square: fp32 rounding of the r- and 256-term sums behind y)
+    if (tid == 0 && lam > 0.f && lam < 3.0e38f) base[ScreenLayout::UBH + k] = sqrtf(lam * (1.0f + 1e-4f)) * (1.0f + 1e-6f);
+}
+
 }  // namespace
+
+int launch_screen_cw(onmf_ctx* c, float* base, int r, int b, const float* H, int k, hipStream_t s) {
+    if (r > 256) return onmf_fail(c, ONMF_ERR_ARG, "screen bound: r=%d > 256", r);
+    hipLaunchKernelGGL(screen_cw_kernel, dim3((b + 255) / 256), dim3(256), 0, s, r, b, H, base);
+    hipLaunchKernelGGL(screen_cw_finish_kernel, dim3(1), dim3(256), 0, s, r, base, k);
+    HIP_TRY(c, hipGetLastError());
+    return ONMF_OK;
+}
 
 int launch_screen_init(onmf_ctx* c, float* base, int r, hipStream_t s) {
     const int keep = (c->screen_r == r) ? 1 : 0;
