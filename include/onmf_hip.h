@@ -223,7 +223,7 @@ double onmf_host_lambda_max(const float* S_host, int n);
  *                          enqueued without host round trips; the full test runs only where the
  *                          bounds straddle stopping_diff.  0: one host decision per sweep.
  *   ONMF_OPT_DICT_KERNEL   0 = pick by shape, 1 = cooperating one-wave workgroups (any d <= 16384),
- *                          2 = one workgroup (d <= 1024).
+ *                          2 = panel kernel: one workgroup per 1024 rows (d <= 16384).
  *   ONMF_OPT_PERSISTENT_SWEEPS != 0 (default): with the screened stopping test, run all sweeps of
  *                          a solve in one launch when its grid (one workgroup per 256 columns)
  *                          fits the chip's CUs; 0: one launch per sweep.

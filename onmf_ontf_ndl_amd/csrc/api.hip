@@ -589,15 +589,14 @@ static int aggregate_impl(onmf_ctx* c, int d, int r, int b, const float* X, int 
 }
 
 static int dict_check(onmf_ctx* c, int r, int d, hipStream_t s) {
-    const int nwg = (d + 63) / 64;
-    if (nwg <= 1 || !c->dict_coop_last) return ONMF_OK;
-    const size_t off = (size_t)r * nwg * sizeof(unsigned long long);
+    if (!c->dict_coop_last) return ONMF_OK;
+    const size_t off = c->dict_flag_off;
     ONMF_TRY(onmf_reserve_pinned(c, 64));
     HIP_TRY(c, hipMemcpyAsync(c->pinned, (char*)c->sync.p + off, sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     if (*(int*)c->pinned != 0)
         return onmf_fail(c, ONMF_ERR_TIMEOUT,
-                         "update_dict: a workgroup waited more than 2 s for the other %d (not co-resident?)", nwg - 1);
+                         "update_dict: a workgroup waited more than 2 s for the others (not co-resident?)");
     return ONMF_OK;
 }
 

@@ -59,6 +59,7 @@ struct onmf_ctx {
     int cu_count = 0;
     DevBuf ddelta;                  // dictionary pass: atom deltas (d x r), one-workgroup kernel
     int dict_kernel = 0;            // 0 = by shape, 1 = cooperative workgroups, 2 = one workgroup
+    size_t dict_flag_off = 0;       // byte offset of that flag in `sync`
     bool dict_coop_last = false;    // the last dictionary pass used the cooperative kernel (its timeout flag is live)
 };
 

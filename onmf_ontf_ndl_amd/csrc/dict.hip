@@ -153,8 +153,14 @@ __global__ __launch_bounds__(256) void dict_panel_kernel(int d, int r, int lda,
                                                          const float* __restrict__ Qt0,   // A^T W^T - B
                                                          const float* __restrict__ Ap,
                                                          const float* __restrict__ Wt,
-                                                         float* __restrict__ WtOut, float* Dt) {
+                                                         float* __restrict__ WtOut, float* Dt, int nwg,
+                                                         u64* granules, int* timeout_flag, long long spin_limit) {
+    // nwg > 1: workgroup g owns rows g * 256 RPT .. (g + 1) * 256 RPT - 1 and the workgroups exchange
+    // their parts of every atom's squared norm (below); everything else is per row.
     constexpr int PW = 16;
+    const int wg = blockIdx.x;
+    const int row0 = wg * (RPT * 256);
+    bool dead = false;                                        // gave up waiting for the other workgroups
     __shared__ __attribute__((aligned(16))) float part[2][16];   // one slot per wave; unused slots stay 0
     __shared__ __attribute__((aligned(16))) float ablk[256];     // the panel's 16 x 16 block of Ap
     const int tid = threadIdx.x;
@@ -176,11 +182,11 @@ __global__ __launch_bounds__(256) void dict_panel_kernel(int d, int r, int lda,
     int voffB[RPT][4];        // MFMA B operand: row p * 256 + wave * 64 + 16 mt + c16, atom offset g4
 #pragma unroll
     for (int p = 0; p < RPT; ++p) {
-        const int i = p * 256 + tid;
+        const int i = row0 + p * 256 + tid;
         voff[p] = i < d ? i * 4 : (int)0x80000000;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
-            const int rowb = p * 256 + wave * 64 + 16 * mt + c16;
+            const int rowb = row0 + p * 256 + wave * 64 + 16 * mt + c16;
             voffB[p][mt] = rowb < d ? (rowb + g4 * d) * 4 : (int)0x80000000;
         }
     }
@@ -309,8 +315,38 @@ __global__ __launch_bounds__(256) void dict_panel_kernel(int d, int r, int lda,
                     anext[m] = v.x; anext[m + 1] = v.y; anext[m + 2] = v.z; anext[m + 3] = v.w;
                 }
             }
-            const float total = __builtin_bit_cast(
+            float total = __builtin_bit_cast(
                 float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, row_total(psum)), 15));
+            if (nwg > 1) {
+                // This workgroup's part goes out as one aligned 8-byte word {tag = j + 1, value}; every
+                // wave then reads all nwg words itself (lane g reads workgroup g's) until the tags match
+                // and adds them in lane order - the same number in every wave of every workgroup.
+                // The wait is bounded; after a timeout the pass runs on without waiting (its result is
+                // discarded: the host reports the flag).
+                if (wave == 0 && lane0) {
+                    const u64 word = ((u64)(unsigned)(j + 1) << 32) | (u64)__float_as_uint(total);
+                    __hip_atomic_store(&granules[(size_t)j * nwg + wg], word, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                }
+                float val = 0.f;
+                const long long t0 = wall_clock64();
+                while (!dead) {
+                    bool ok = true;
+                    if (lane < nwg) {
+                        const u64 x = __hip_atomic_load(&granules[(size_t)j * nwg + lane], __ATOMIC_RELAXED,
+                                                        __HIP_MEMORY_SCOPE_AGENT);
+                        ok = (unsigned)(x >> 32) == (unsigned)(j + 1);
+                        val = __uint_as_float((unsigned)x);
+                    }
+                    if (__all(ok)) break;
+                    if (wall_clock64() - t0 > spin_limit) {
+                        dead = true;                          // wave-uniform (one clock value per wave)
+                        if (lane0) atomicExch(timeout_flag, 1);
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                total = wave_sum_uniform(lane < nwg ? val : 0.f);
+            }
             const float scale = total > 1.0f ? __builtin_amdgcn_rsqf(total) : 1.0f;
 #pragma unroll
             for (int p = 0; p < RPT; ++p) {
@@ -340,27 +376,44 @@ __global__ void zero_u64_kernel(u64* p, size_t n) {
 int launch_dict_pass(onmf_ctx* c, int d, int r, const float* Win, const float* A, const float* B,
                      float* Wout, hipStream_t s) {
     c->dict_coop_last = false;
-    if (d <= 1024 && c->dict_kernel != 1) {
+    if (d <= 16 * 1024 && c->dict_kernel != 1) {
+        // one workgroup per 1024 rows; several exchange the atoms' norms (they are few: co-resident)
+        const int nwg = (d + 1023) / 1024;
+        const int lda = (r + 15) / 16 * 16;
         // Qt0[j][i] = sum_k A[k][j] * W[i][k]
         ONMF_TRY(onmf_reserve(c, c->qt, (size_t)r * d * sizeof(float), "dictionary Qt"));
         float* Qt = (float*)c->qt.p;
         ONMF_TRY(launch_gemm(c, /*a_km=*/true, /*b_kn=*/false, r, d, r, A, r, Win, r, 1.f, -1.f, B,
                              Qt, d, s, &c->slab_side));               // Qt = A^T W^T - B
-        const int lda = (r + 15) / 16 * 16;
         ONMF_TRY(onmf_reserve(c, c->ddelta, (3 * (size_t)d * r + (size_t)r * lda + 16) * sizeof(float),
                               "dictionary deltas"));
         float* Ap = (float*)c->ddelta.p;             // 64-byte aligned rows
         float* Dt = Ap + (size_t)r * lda;
         float* Wt = Dt + (size_t)d * r;              // W^T in, r x d
         float* WtOut = Wt + (size_t)d * r;
+        u64* gran = nullptr;
+        int* flag = nullptr;
+        if (nwg > 1) {
+            const size_t ngran = (size_t)lda * nwg;                  // padded atoms exchange too
+            ONMF_TRY(onmf_reserve(c, c->sync, ngran * sizeof(u64) + 64, "dictionary sync words"));
+            gran = (u64*)c->sync.p;
+            c->dict_flag_off = ngran * sizeof(u64);
+            flag = (int*)((char*)c->sync.p + c->dict_flag_off);
+            hipLaunchKernelGGL(zero_u64_kernel, dim3((unsigned)((ngran + 8 + 255) / 256)), dim3(256), 0, s, gran,
+                               ngran + 8);
+            HIP_TRY(c, hipGetLastError());
+            c->dict_coop_last = true;
+        }
         ONMF_TRY(launch_transpose(d, r, Win, Wt, s));
         hipLaunchKernelGGL(dict_pad_kernel, dim3(r), dim3(64), 0, s, r, lda, A, Ap);
         HIP_TRY(c, hipGetLastError());
-        // 256 threads, thread t owns rows t, t + 256, ...
-        const int rpt = (d + 255) / 256;
+        // 256 threads, thread t owns rows t, t + 256, ... of its workgroup's 1024
+        const int rpt = nwg > 1 ? 4 : (d + 255) / 256;
         const int nt = rpt > 1 ? 256 : (d + 63) / 64 * 64;
+        const long long spin_limit = 200000000LL;   // 2 s of the 100 MHz wall clock
 #define PANEL_CASE(RPTV)                                                                              \
-    hipLaunchKernelGGL((dict_panel_kernel<RPTV>), dim3(1), dim3(nt), 0, s, d, r, lda, Qt, Ap, Wt, WtOut, Dt)
+    hipLaunchKernelGGL((dict_panel_kernel<RPTV>), dim3(nwg), dim3(nt), 0, s, d, r, lda, Qt, Ap, Wt, WtOut, Dt, \
+                       nwg, gran, flag, spin_limit)
         if (rpt <= 1) PANEL_CASE(1);
         else if (rpt <= 2) PANEL_CASE(2);
         else PANEL_CASE(4);
@@ -369,7 +422,7 @@ int launch_dict_pass(onmf_ctx* c, int d, int r, const float* Win, const float* A
         return launch_transpose(r, d, WtOut, Wout, s);
     }
     if (c->dict_kernel == 2)
-        return onmf_fail(c, ONMF_ERR_ARG, "update_dict: the one-workgroup kernel covers d <= 1024 (d=%d)", d);
+        return onmf_fail(c, ONMF_ERR_ARG, "update_dict: the panel kernel covers d <= 16384 (d=%d)", d);
     c->dict_coop_last = true;
     const int nwg = (d + 63) / 64;
     if (nwg > 256)
@@ -387,7 +440,8 @@ int launch_dict_pass(onmf_ctx* c, int d, int r, const float* Win, const float* A
     const size_t ngran = (size_t)r * nwg;
     ONMF_TRY(onmf_reserve(c, c->sync, ngran * sizeof(u64) + 64, "dictionary sync words"));
     u64* gran = (u64*)c->sync.p;
-    int* flag = (int*)((char*)c->sync.p + ngran * sizeof(u64));
+    c->dict_flag_off = ngran * sizeof(u64);
+    int* flag = (int*)((char*)c->sync.p + c->dict_flag_off);
     hipLaunchKernelGGL(zero_u64_kernel, dim3((unsigned)((ngran + 8 + 255) / 256)), dim3(256), 0, s, gran,
                        ngran + 8);
     HIP_TRY(c, hipGetLastError());

@@ -311,11 +311,13 @@ def test_step_against_oracle(eng, orc, d, r, b, kernel):
 
 
 @pytest.mark.parametrize("kernel", [1, 2])
-@pytest.mark.parametrize("shape", [(1500, 48), (64, 16), (1024, 256), (2500, 40), (700, 23), (300, 100), (33, 7)])
+@pytest.mark.parametrize("shape", [(1500, 48), (64, 16), (1024, 256), (2500, 40), (700, 23), (300, 100), (33, 7),
+                                   (4096, 64), (5000, 17)])
 def test_update_dict_both_kernels(eng, orc, kernel, shape):
-    """The dictionary pass with cooperating workgroups (1; d = 1500 -> 24 of them) and inside one
-    workgroup (2; d <= 1024, one to four rows per thread), against the oracle."""
-    if kernel == 2 and shape[0] > 1024:
+    """The dictionary pass with cooperating one-wave workgroups (1; d = 1500 -> 24 of them) and with the
+    panel kernel (2; one workgroup per 1024 rows, which exchange the atoms' norms when there are
+    several), against the oracle."""
+    if kernel == 2 and shape[0] > 16384:
         with pytest.raises(Exception):
             eng.set_option(6, 2)
             try:
