@@ -88,7 +88,9 @@ int onmf_reserve_pinned(onmf_ctx* c, size_t bytes);
 // b_kn: B(k,n)=B[k*ldb+n] else B[n*ldb+k].  Cin may be null when beta == 0; Cin may alias C.
 int launch_gemm(onmf_ctx* c, bool a_km, bool b_kn, int M, int N, int K, const float* A, int lda,
                 const float* B, int ldb, float alpha, float beta, const float* Cin, float* C,
-                int ldc, hipStream_t s, DevBuf* slab = nullptr);
+                int ldc, hipStream_t s, DevBuf* slab = nullptr, bool no_split = false);
+// (no_split: one workgroup per output tile whatever the shape - for a product that starts a latency
+// chain beside a chip-filling kernel, where a second launch to add slabs costs more than it saves)
 
 // What a probing sweep launch needs of the stopping-test screen (screen.hip).
 struct ScreenDev {

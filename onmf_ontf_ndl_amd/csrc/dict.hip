@@ -384,7 +384,7 @@ int launch_dict_pass(onmf_ctx* c, int d, int r, const float* Win, const float* A
         ONMF_TRY(onmf_reserve(c, c->qt, (size_t)r * d * sizeof(float), "dictionary Qt"));
         float* Qt = (float*)c->qt.p;
         ONMF_TRY(launch_gemm(c, /*a_km=*/true, /*b_kn=*/false, r, d, r, A, r, Win, r, 1.f, -1.f, B,
-                             Qt, d, s, &c->slab_side));               // Qt = A^T W^T - B
+                             Qt, d, s, &c->slab_side, /*no_split=*/true));   // Qt = A^T W^T - B
         ONMF_TRY(onmf_reserve(c, c->ddelta, (3 * (size_t)d * r + (size_t)r * lda + 16) * sizeof(float),
                               "dictionary deltas"));
         float* Ap = (float*)c->ddelta.p;             // 64-byte aligned rows

@@ -318,7 +318,7 @@ int run(onmf_ctx* c, const GemmParams& p, dim3 grid, hipStream_t s) {
 
 int launch_gemm(onmf_ctx* c, bool a_km, bool b_kn, int M, int N, int K, const float* A, int lda,
                 const float* B, int ldb, float alpha, float beta, const float* Cin, float* C,
-                int ldc, hipStream_t s, DevBuf* slab) {
+                int ldc, hipStream_t s, DevBuf* slab, bool no_split) {
     if (!slab) slab = &c->slab;
     if (M <= 0 || N <= 0 || K < 0) return onmf_fail(c, ONMF_ERR_ARG, "gemm: bad shape %dx%dx%d", M, N, K);
     if (beta != 0.f && Cin == nullptr) return onmf_fail(c, ONMF_ERR_ARG, "gemm: beta without Cin");
@@ -333,7 +333,7 @@ int launch_gemm(onmf_ctx* c, bool a_km, bool b_kn, int M, int N, int K, const fl
     const int tiles = tiles_m * tiles_n;
     const int ktiles = (K + BK - 1) / BK;
     int splits = 1;
-    if (tiles < 256 && ktiles >= 4) {
+    if (tiles < 256 && ktiles >= 4 && !no_split) {
         // few tiles: one workgroup per CU is enough, and half as many slabs for the reduction to read
         splits = ((tiles <= 4 ? 256 : 512) + tiles - 1) / tiles;
         const int max_by_k = ktiles / 2;          // at least 2 k-tiles of work per slab
