@@ -205,3 +205,41 @@ def test_train_dict_from_random_patches_keeps_the_constraint_set(eng):
     assert W.shape == (48, 8)
     assert W.min() >= 0 and np.linalg.norm(W, axis=0).max() <= 1 + 1e-5
     assert rec.nmf.history > 0
+
+
+def test_tensor_reconstructor_patch_tensors_and_color_reconstruction(eng, io):
+    """image_reconstruction_tensor.py: patch tensors, and the per-window positive lasso (alpha = 1) as one
+    batched solve, against the oracle's coordinate-descent solution of the same problem + running-mean fold."""
+    from onmf_ontf_ndl_amd.image_reconstruction_tensor import Image_Reconstructor
+    from oracle import onmf_oracle as orc
+    rs = np.random.RandomState(31)
+    A = rs.rand(13, 15, 3)
+    k, res = 4, 2
+    rec = Image_Reconstructor(A, n_components=7, patch_size=k, num_patches=20, is_color=True)
+    np.random.seed(6)
+    T = rec.extract_random_patches()
+    np.random.seed(6)
+    corners = io.random_corners(A.shape, k, 20)
+    ref = io.random_patches(A, k, corners).reshape(k * k, 3, 20)
+    assert T.shape == (16, 3, 20)
+    assert np.array_equal(T, ref.astype(np.float32).astype(np.float64))
+    W = rs.rand(k * k * 3, 7)
+    W /= np.linalg.norm(W, axis=0)
+    rec.W = W
+    out = rec.reconstruct_image_color(A, recons_resolution=res)
+    X = io.grid_patches(A, k, res, drop_last=True)
+    H = orc.lasso_nonneg_code(X, W, alpha=1, solver="cd").T
+    ref_img, count = io.fold_patches(W @ H, A.shape, k, res, drop_last=True)
+    assert np.array_equal(rec.A_overlap_count, count)
+    assert relerr(out, ref_img) <= 2e-4
+
+
+def test_tensor_reconstructor_trains_along_a_mode(eng):
+    from onmf_ontf_ndl_amd.image_reconstruction_tensor import Image_Reconstructor
+    rs = np.random.RandomState(32)
+    A = rs.rand(20, 22, 3)
+    np.random.seed(9)
+    rec = Image_Reconstructor(A, n_components=5, iterations=2, sub_iterations=3, block_iterations=5, batch_size=8,
+                              num_patches=30, patch_size=3, is_color=True)
+    W = rec.train_dict(mode=2, learn_joint_dict=True)
+    assert W.shape == (27, 5) and W.min() >= 0 and np.linalg.norm(W, axis=0).max() <= 1 + 1e-5
