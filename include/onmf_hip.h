@@ -184,8 +184,15 @@ int onmf_surrogate_loss(onmf_ctx* ctx, int d, int r, const float* W, const float
  * Randomness is Philox4x32-10 keyed by `seed`, a pure function of (chain, step_offset + s, slot):
  * a later call continues the same chains when it passes step_offset = steps already taken.
  * (The reference draws from NumPy's global generator; its stream cannot be followed on the device.)
+ * emb_trace (device int32[n_chains*steps*k], nullable): the embedding behind every patch, row
+ * c*steps + s - what reconstruct_network needs to put a patch back on the graph (:477-479).
  * onmf_ndl_init_embeddings: emb[c] = tree_sample(motif, pivots[c]); pivots == NULL draws each pivot
  * uniformly (train_dict, :351-352).
+ * onmf_ndl_accumulate_edges: the edge-wise averaging of reconstruct_network (:477-491) as dense sums:
+ * for every patch t and entry (q, r), sum[a*n + b] += R[(q*k + r)*ldr + t] and count[a*n + b] += 1 with
+ * (a, b) = (emb_trace[t][q], emb_trace[t][r]); sum and count are n x n device floats that the caller
+ * zeroes first (the reference's running mean is sum / count).  Float atomics: the order of the
+ * additions, hence the last bits of sum, can differ between runs.
  */
 #define ONMF_NDL_GLAUBER 0
 #define ONMF_NDL_PIVOT 1
@@ -195,7 +202,9 @@ int onmf_ndl_init_embeddings(onmf_ctx* ctx, int n_nodes, const int32_t* row_ptr,
 int onmf_ndl_sample_patches(onmf_ctx* ctx, int n_nodes, const int32_t* row_ptr, const int32_t* nbr,
                             int k, const int32_t* motif, int chain_kind, int n_chains, int steps,
                             int32_t* emb, uint64_t seed, uint64_t step_offset, float* X, int ldx,
-                            void* stream);
+                            int32_t* emb_trace, void* stream);
+int onmf_ndl_accumulate_edges(onmf_ctx* ctx, int n_nodes, int k, int n_patches, const int32_t* emb_trace,
+                              const float* R, int ldr, float* sum, float* count, void* stream);
 
 /* U[0,1) fill, the device stand-in for np.random.rand (src/onmf.py:190, :246). */
 int onmf_fill_uniform(onmf_ctx* ctx, float* out, size_t n, uint64_t seed, void* stream);

@@ -841,7 +841,7 @@ int onmf_ndl_init_embeddings(onmf_ctx* c, int n_nodes, const int32_t* row_ptr, c
     if (!c) return ONMF_ERR_ARG;
     ONMF_TRY(ndl_args(c, "ndl_init_embeddings", n_nodes, row_ptr, nbr, k, motif, n_chains, emb));
     HIP_TRY(c, hipSetDevice(c->device));
-    if (launch_ndl_chains(n_nodes, row_ptr, nbr, k, motif, 2, n_chains, 0, emb, pivots, seed, 0, nullptr, 0,
+    if (launch_ndl_chains(n_nodes, row_ptr, nbr, k, motif, 2, n_chains, 0, emb, pivots, seed, 0, nullptr, 0, nullptr,
                           (hipStream_t)stream) != ONMF_OK)
         return onmf_fail(c, ONMF_ERR_HIP, "ndl_init_embeddings: launch failed");
     return ONMF_OK;
@@ -849,7 +849,8 @@ int onmf_ndl_init_embeddings(onmf_ctx* c, int n_nodes, const int32_t* row_ptr, c
 
 int onmf_ndl_sample_patches(onmf_ctx* c, int n_nodes, const int32_t* row_ptr, const int32_t* nbr, int k,
                             const int32_t* motif, int chain_kind, int n_chains, int steps, int32_t* emb,
-                            uint64_t seed, uint64_t step_offset, float* X, int ldx, void* stream) {
+                            uint64_t seed, uint64_t step_offset, float* X, int ldx, int32_t* emb_trace,
+                            void* stream) {
     if (!c) return ONMF_ERR_ARG;
     ONMF_TRY(ndl_args(c, "ndl_sample_patches", n_nodes, row_ptr, nbr, k, motif, n_chains, emb));
     if (chain_kind != ONMF_NDL_GLAUBER && chain_kind != ONMF_NDL_PIVOT)
@@ -859,8 +860,19 @@ int onmf_ndl_sample_patches(onmf_ctx* c, int n_nodes, const int32_t* row_ptr, co
                          ldx);
     HIP_TRY(c, hipSetDevice(c->device));
     if (launch_ndl_chains(n_nodes, row_ptr, nbr, k, motif, chain_kind, n_chains, steps, emb, nullptr, seed, step_offset,
-                          X, ldx, (hipStream_t)stream) != ONMF_OK)
+                          X, ldx, emb_trace, (hipStream_t)stream) != ONMF_OK)
         return onmf_fail(c, ONMF_ERR_HIP, "ndl_sample_patches: launch failed");
+    return ONMF_OK;
+}
+
+int onmf_ndl_accumulate_edges(onmf_ctx* c, int n_nodes, int k, int n_patches, const int32_t* emb_trace, const float* R,
+                              int ldr, float* sum, float* count, void* stream) {
+    if (!c) return ONMF_ERR_ARG;
+    if (n_nodes <= 0 || k < 1 || k > 64 || n_patches <= 0 || !emb_trace || !R || !sum || !count || ldr < n_patches)
+        return onmf_fail(c, ONMF_ERR_ARG, "ndl_accumulate_edges: bad arguments");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (launch_ndl_edge_accumulate(n_nodes, k, n_patches, emb_trace, R, ldr, sum, count, (hipStream_t)stream) != ONMF_OK)
+        return onmf_fail(c, ONMF_ERR_HIP, "ndl_accumulate_edges: launch failed");
     return ONMF_OK;
 }
 

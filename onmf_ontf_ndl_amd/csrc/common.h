@@ -139,7 +139,9 @@ int launch_patch_fold(const float* R, int ldr, int h, int w, int ch, int k, int 
 // Motif-sampling chains (ndl.hip): mode 0 Glauber, 1 pivot, 2 initial embedding from pivots.
 int launch_ndl_chains(int n, const int* row_ptr, const int* nbr, int k, const int* motif, int mode, int n_chains,
                       int steps, int* emb, const int* pivots, uint64_t seed, uint64_t step0, float* X, int ldx,
-                      hipStream_t s);
+                      int* emb_trace, hipStream_t s);
+int launch_ndl_edge_accumulate(int n, int k, int T, const int* emb_trace, const float* R, int ldr, float* sum,
+                               float* count, hipStream_t s);
 
 // Stopping-test screen: state layout and kernels.
 constexpr int SCREEN_MAX_SWEEPS = 64;

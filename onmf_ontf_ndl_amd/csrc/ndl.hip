@@ -80,7 +80,8 @@ __global__ __launch_bounds__(64) void ndl_chain_kernel(int n, const int* __restr
                                                        const int* __restrict__ nbr, int k,
                                                        const int* __restrict__ motif, int mode, int steps,
                                                        int* __restrict__ emb, const int* __restrict__ pivots,
-                                                       uint64_t seed, uint64_t step0, float* __restrict__ X, int ldx) {
+                                                       uint64_t seed, uint64_t step0, float* __restrict__ X, int ldx,
+                                                       int* __restrict__ emb_trace) {
     const int lane = threadIdx.x;
     const uint32_t chain = blockIdx.x;
     // motif rows / columns of this lane's node as bit masks
@@ -188,6 +189,7 @@ __global__ __launch_bounds__(64) void ndl_chain_kernel(int n, const int* __restr
         }
         // the patch: a2[q][r] = has_edge(emb[q], emb[r]) (:302-305), column chain*steps + s
         const size_t col = (size_t)chain * steps + s;
+        if (emb_trace != nullptr && lane < k) emb_trace[col * k + lane] = my;
         for (int base = 0; base < k * k; base += 64) {      // (uniform trip count: every lane takes part in the shuffles)
             const int e = base + lane;
             const bool valid = e < k * k;
@@ -199,12 +201,36 @@ __global__ __launch_bounds__(64) void ndl_chain_kernel(int n, const int* __restr
     if (lane < k) emb[(size_t)chain * k + lane] = my;
 }
 
+// Edge-wise accumulation of reconstructed patches (reconstruct_network, network_reconstruction_nx.py:
+// 477-491): entry (q, r) of patch t belongs to the ordered node pair (emb_t[q], emb_t[r]); its values
+// are averaged per pair.  Dense n x n sums and counts (the running mean of the reference is their
+// quotient), float atomics: one thread per (entry, patch), patches fastest (coalesced reads of R).
+__global__ __launch_bounds__(256) void ndl_edge_accumulate_kernel(int n, int k, int T, const int* __restrict__ emb_trace,
+                                                                  const float* __restrict__ R, int ldr,
+                                                                  float* __restrict__ sum, float* __restrict__ count) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int e = blockIdx.y;
+    if (t >= T) return;
+    const int q = e / k, r = e - q * k;
+    const int a = emb_trace[(size_t)t * k + q], b = emb_trace[(size_t)t * k + r];
+    const size_t at = (size_t)a * n + b;
+    atomicAdd(sum + at, R[(size_t)e * ldr + t]);
+    atomicAdd(count + at, 1.0f);
+}
+
 }  // namespace
+
+int launch_ndl_edge_accumulate(int n, int k, int T, const int* emb_trace, const float* R, int ldr, float* sum,
+                               float* count, hipStream_t s) {
+    hipLaunchKernelGGL(ndl_edge_accumulate_kernel, dim3((T + 255) / 256, k * k), dim3(256), 0, s, n, k, T, emb_trace, R,
+                       ldr, sum, count);
+    return hipGetLastError() == hipSuccess ? ONMF_OK : ONMF_ERR_HIP;
+}
 
 int launch_ndl_chains(int n, const int* row_ptr, const int* nbr, int k, const int* motif, int mode, int n_chains,
                       int steps, int* emb, const int* pivots, uint64_t seed, uint64_t step0, float* X, int ldx,
-                      hipStream_t s) {
+                      int* emb_trace, hipStream_t s) {
     hipLaunchKernelGGL(ndl_chain_kernel, dim3(n_chains), dim3(64), 0, s, n, row_ptr, nbr, k, motif, mode, steps, emb,
-                       pivots, seed, step0, X, ldx);
+                       pivots, seed, step0, X, ldx, emb_trace);
     return hipGetLastError() == hipSuccess ? ONMF_OK : ONMF_ERR_HIP;
 }

@@ -281,9 +281,9 @@ class Engine:
         _lib.check(rc, self.ctx, "onmf_ndl_init_embeddings")
         return emb
 
-    def ndl_sample_patches(self, graph, motif, emb, steps, glauber=True, seed=0, step_offset=0):
+    def ndl_sample_patches(self, graph, motif, emb, steps, glauber=True, seed=0, step_offset=0, want_trace=False):
         """Advance every chain ``steps`` times; returns X (k*k x n_chains*steps) and updates ``emb`` in place
-        (network_reconstruction_nx.py:315-329)."""
+        (network_reconstruction_nx.py:315-329).  ``want_trace``: also the embedding behind every patch."""
         i32 = self.torch.int32
         motif = self.dev(motif, i32)
         k = motif.shape[0]
@@ -291,12 +291,26 @@ class Engine:
             raise ValueError("emb must be a contiguous int32 (n_chains, %d) tensor" % k)
         n_chains = emb.shape[0]
         X = self.empty(k * k, n_chains * int(steps))
+        trace = self.torch.empty(n_chains * int(steps), k, dtype=i32, device=self.device) if want_trace else None
         rc = self.lib.onmf_ndl_sample_patches(self.ctx, graph["n"], _ptr(graph["row_ptr"]), _ptr(graph["nbr"]), k,
                                               _ptr(motif), _lib.NDL_GLAUBER if glauber else _lib.NDL_PIVOT, n_chains,
                                               int(steps), _ptr(emb), C.c_uint64(seed), C.c_uint64(step_offset),
-                                              _ptr(X), X.stride(0), self.stream())
+                                              _ptr(X), X.stride(0), _ptr(trace), self.stream())
         _lib.check(rc, self.ctx, "onmf_ndl_sample_patches")
-        return X
+        return (X, trace) if want_trace else X
+
+    def ndl_accumulate_edges(self, n_nodes, trace, R):
+        """Per ordered node pair: sum and count of the patch entries that fall on it
+        (network_reconstruction_nx.py:477-491).  Dense (n x n) tensors."""
+        T, k = trace.shape
+        if R.shape[0] != k * k or R.shape[1] != T:
+            raise ValueError("R must be (%d, %d)" % (k * k, T))
+        total = self.zeros(n_nodes, n_nodes)
+        count = self.zeros(n_nodes, n_nodes)
+        rc = self.lib.onmf_ndl_accumulate_edges(self.ctx, int(n_nodes), k, T, _ptr(trace), _ptr(R), R.stride(0),
+                                                _ptr(total), _ptr(count), self.stream())
+        _lib.check(rc, self.ctx, "onmf_ndl_accumulate_edges")
+        return total, count
 
     def rand(self, rows, cols, seed=None):
         out = self.empty(rows, cols)

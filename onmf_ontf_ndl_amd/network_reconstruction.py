@@ -217,5 +217,41 @@ class Network_Reconstructor():
         self.emb = emb
         return self.W
 
-    def reconstruct_network(self, recons_iter=100):
-        raise NotImplementedError("reconstruct_network (network_reconstruction_nx.py:444-511) is not carried over")
+    def reconstruct_network(self, recons_iter=100, *, return_weights=False, cd_tol=1e-6, cd_max_sweeps=4000):
+        """``recons_iter`` chain steps; every patch is coded against the dictionary (positive lasso with
+        alpha = 0, i.e. non-negative least squares - the reference's LassoLars call), reconstructed and
+        averaged onto the ordered node pairs its embedding covers; pairs whose mean rounds to 1 become the
+        edges of the result (network_reconstruction_nx.py:444-511).  All patches are coded in one batched
+        solve and accumulated by one kernel into dense n x n sums.  Returns a ``networkx.Graph`` when
+        networkx is importable, else an (m, 2) array of node-label pairs; ``return_weights`` adds the
+        (n x n) mean and count matrices (node order = ``self.nodes``)."""
+        eng = self._engine()
+        n = len(self.nodes)
+        if n > 46000:
+            raise ValueError("reconstruct_network keeps dense %d x %d accumulators; the graph is too large" % (n, n))
+        B = self._check_motif(self.path_adj(self.k1, self.k2))
+        emb = eng.ndl_init_embeddings(self._g(), B, 1, pivots=None, seed=self.seed + self._next_steps(1))
+        X, trace = eng.ndl_sample_patches(self._g(), B, emb, int(recons_iter), glauber=self.is_glauber_recons,
+                                          seed=self.seed, step_offset=self._next_steps(recons_iter), want_trace=True)
+        Wd = eng.dev(self.W)
+        from . import _lib
+        H0 = eng.zeros(Wd.shape[1], X.shape[1])
+        H, _, _ = eng.sparse_code(X, Wd, H0=H0, alpha=0.0, sub_iter=cd_max_sweeps, stopping_diff=cd_tol,
+                                  mode=_lib.CODER_EXACT_CD)
+        total, count = eng.ndl_accumulate_edges(n, trace, eng.patch_product(Wd, H))
+        mean = eng.torch.where(count > 0, total / count.clamp(min=1), eng.torch.zeros_like(total))
+        keep = eng.torch.round(mean) > 0                       # np.round: exactly 0.5 goes to 0
+        pairs = eng.torch.nonzero(keep | keep.t()).cpu().numpy()
+        pairs = pairs[pairs[:, 0] <= pairs[:, 1]]
+        edges = np.stack([self.nodes[pairs[:, 0]], self.nodes[pairs[:, 1]]], axis=1) if len(pairs) else \
+            np.zeros((0, 2), dtype=self.nodes.dtype)
+        self.emb = self.nodes[emb.cpu().numpy()[0]]
+        try:
+            import networkx as nx
+            out = nx.Graph()
+            out.add_edges_from(map(tuple, edges.tolist()))
+        except ImportError:                                   # pragma: no cover
+            out = edges
+        if return_weights:
+            return out, _out(mean, False), _out(count, False)
+        return out

@@ -164,3 +164,26 @@ def sample_patches(G, B, emb, glauber, steps, seed, chain=0, step_offset=0):
         emb = glauber_update(G, B, emb, seed, step, chain) if glauber else pivot_update(G, B, emb, seed, step, chain)
         X[:, s] = patch(G, emb).reshape(-1)
     return X, emb
+
+
+def reconstruct_network(G, B, W, emb, glauber, recons_iter, seed, chain=0, step_offset=0, coder=None):
+    """The loop of ``reconstruct_network`` (network_reconstruction_nx.py:464-491): per chain step, code
+    the patch (``coder(patch_column, W) -> code column``; the reference uses positive LassoLars with
+    alpha = 0), rebuild it and fold its entries into a running mean per ordered node pair.  Returns
+    (mean, count) as dicts keyed by (a, b), the thresholded undirected edge set (:500-508) and the
+    final embedding."""
+    k = B.shape[0]
+    mean, count = {}, {}
+    for s in range(recons_iter):
+        step = step_offset + s
+        emb = glauber_update(G, B, emb, seed, step, chain) if glauber else pivot_update(G, B, emb, seed, step, chain)
+        x = patch(G, emb).reshape(-1, 1)
+        rec = (W @ coder(x, W)).reshape(k, k)
+        for q in range(k):
+            for r in range(k):
+                key = (emb[q], emb[r])
+                j = count.get(key, 0)
+                mean[key] = (j * mean.get(key, 0.0) + rec[q, r]) / (j + 1)
+                count[key] = j + 1
+    edges = {tuple(sorted(key)) for key, v in mean.items() if np.round(v) > 0}
+    return mean, count, edges, emb

@@ -149,3 +149,36 @@ def test_network_reconstructor_facade(eng, nd):
     e8 = many.initial_embedding(B)
     X8, e8b = many.get_patches_glauber(B, e8)
     assert e8.shape == (8, 7) and X8.shape == (49, 64) and e8b.shape == (8, 7)
+
+
+def test_reconstruct_network_equals_the_sequential_loop(eng, nd):
+    """Chain -> non-negative least squares per patch -> edge-wise running mean, against the oracle's
+    sequential restatement fed the same draws (means to 1e-4; the thresholded edge sets equal wherever
+    a mean is not within 1e-3 of one half)."""
+    from onmf_ontf_ndl_amd.network_reconstruction import Network_Reconstructor
+    from oracle import onmf_oracle as orc
+    G = small_graph(nd, 40, 70, seed=12)
+    edges = np.array([(a, b) for a in range(G.n) for b in G.nbrs[a] if a < b])
+    rs = np.random.RandomState(3)
+    k1, k2, r, T = 0, 5, 8, 300
+    rec = Network_Reconstructor(edges, n_components=r, k1=k1, k2=k2, is_glauber_recons=False, seed=17)
+    idx = {int(v): i for i, v in enumerate(rec.nodes)}           # node label -> oracle index is the identity here
+    W = rs.rand((k1 + k2 + 1) ** 2, r)
+    W /= np.linalg.norm(W, axis=0)
+    rec.W = W
+    out, mean, count = rec.reconstruct_network(recons_iter=T, return_weights=True)
+    # the same chain on the CPU: graph in the facade's node order
+    Gf = nd.Graph(len(rec.nodes), [(idx[int(a)], idx[int(b)]) for a, b in edges])
+    B = nd.path_adj(k1, k2)
+    emb0 = nd.init_embedding(Gf, B, 17 + 0, 0)
+    coder = lambda x, Wm: orc.lasso_nonneg_code(x, Wm, alpha=0, solver="cd").T
+    m_ref, c_ref, e_ref, _ = nd.reconstruct_network(Gf, B, W, emb0, False, T, 17, chain=0, step_offset=1, coder=coder)
+    assert int(count.sum()) == T * (k1 + k2 + 1) ** 2
+    worst = 0.0
+    for (a, b), v in m_ref.items():
+        assert count[a, b] == c_ref[(a, b)]
+        worst = max(worst, abs(mean[a, b] - v))
+    assert worst < 1e-4
+    got = {tuple(sorted((idx[int(a)], idx[int(b)]))) for a, b in out.edges}
+    shaky = {tuple(sorted(key)) for key, v in m_ref.items() if abs(v - 0.5) < 1e-3}
+    assert got - shaky == e_ref - shaky
