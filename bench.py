@@ -25,7 +25,7 @@ if ROOT not in sys.path:
 WORKLOADS = {
     # name: (d, r, b)
     "headline": (1024, 256, 65536),      # the shape the 50 %-of-roofline target is quoted on
-    "c2": (1024, 64, 8192),              # BASELINE.json configs[1]
+    "c2": (1024, 64, 8192),              # the reference-scale case (r = 64)
     "c4": (4096, 256, 65536),            # configs[3], per GPU
     "c3": (1200, 100, 8192),
     "c1": (100, 16, 1000),
