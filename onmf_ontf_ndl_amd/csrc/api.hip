@@ -222,6 +222,7 @@ int onmf_destroy(onmf_ctx* c) {
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_rec) (void)hipEventDestroy(c->ev_rec);
+    if (c->ev_mid) (void)hipEventDestroy(c->ev_mid);
     if (c->side) (void)hipStreamDestroy(c->side);
     if (c->prep) (void)hipStreamDestroy(c->prep);
     if (c->ev_prep_fork) (void)hipEventDestroy(c->ev_prep_fork);
@@ -659,17 +660,28 @@ int onmf_step(onmf_ctx* c, int d, int r, int b, const float* X, int ldx, const f
         }
         HIP_TRY(c, hipEventRecord(c->ev_fork, s));
         HIP_TRY(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
-        int rc = launch_dict_pass(c, d, r, W_in, A_in, B_in, W_out, c->side);
-        hipError_t e1 = hipEventRecord(c->ev_join, c->side);
+        // The pass is longer than the W^T X product it hides under, and while it holds a CU the sweeps
+        // (one workgroup per CU, all of them needed) cannot start.  It runs in two parts: the first half
+        // of the atoms beside W^T X, the second beside the aggregate products after the sweeps.
+        const bool split = dict_pass_splits(c, d, r);
+        int rc = launch_dict_pass(c, d, r, W_in, A_in, B_in, W_out, c->side, split ? 1 : 0);
         int rc2 = ONMF_OK;
-        bool agg_done = false;
+        bool agg_done = false, second_posted = !split;
         const std::function<int()> agg = [&]() {
+            if (!second_posted) {
+                second_posted = true;
+                if (!c->ev_mid) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_mid, hipEventDisableTiming));
+                HIP_TRY(c, hipEventRecord(c->ev_mid, s));                 // behind the sweeps
+                HIP_TRY(c, hipStreamWaitEvent(c->side, c->ev_mid, 0));
+                ONMF_TRY(launch_dict_pass(c, d, r, W_in, A_in, B_in, W_out, c->side, 2));
+            }
             return aggregate_impl(c, d, r, b, X, ldx, H, w, A_in, B_in, C_in, A_out, B_out, C_out, s);
         };
         if (rc == ONMF_OK)
             rc2 = sparse_code_impl(c, d, r, b, X, ldx, W_in, H0, seed, alpha, sub_iter, stopping_diff,
                                    ONMF_CODER_DAMPED, H, sweeps_done, dist_trace, s, &agg, &agg_done);
         if (rc == ONMF_OK && rc2 == ONMF_OK && !agg_done) rc2 = agg();
+        hipError_t e1 = hipEventRecord(c->ev_join, c->side);
         // always rejoin, also on an error path, so the side stream never outlives the call's buffers
         hipError_t e2 = hipStreamWaitEvent(s, c->ev_join, 0);
         if (rc != ONMF_OK) return rc;

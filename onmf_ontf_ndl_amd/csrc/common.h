@@ -47,7 +47,7 @@ struct onmf_ctx {
     DevBuf screen;                  // stopping-test screen state (ScreenLayout)
     DevBuf slab_side;               // split-K slabs of products issued on the side stream
     hipStream_t side = nullptr;     // dictionary pass runs here, beside the code solve
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_rec = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_rec = nullptr, ev_mid = nullptr;
     hipStream_t prep = nullptr;     // the solve's small preparations run here, beside the W^T X product
     hipEvent_t ev_prep_fork = nullptr, ev_prep_join = nullptr;
     DevBuf slab_prep;               // split-K slabs of products issued on the preparation stream
@@ -274,8 +274,11 @@ int launch_screen_refresh(onmf_ctx* c, float* base, int r, int b, const float* H
 // stored as that sweep's bound, and one power step of the vector it uses
 int launch_screen_cw(onmf_ctx* c, float* base, int r, int b, const float* H, int k, hipStream_t s);
 
+// part 0: the whole pass.  Parts 1 and 2 (dict_pass_splits): the atoms before / from the middle panel
+// boundary, as two launches with the same arguments; W_out is complete after part 2.
 int launch_dict_pass(onmf_ctx* c, int d, int r, const float* Win, const float* A, const float* B,
-                     float* Wout, hipStream_t s);
+                     float* Wout, hipStream_t s, int part = 0);
+bool dict_pass_splits(const onmf_ctx* c, int d, int r);
 
 int launch_fill_uniform(float* out, size_t n, uint64_t seed, hipStream_t s);
 int launch_gather_columns(int d, int n, const float* X, int ldx, const long long* idx, int b,

@@ -154,7 +154,11 @@ __global__ __launch_bounds__(256) void dict_panel_kernel(int d, int r, int lda,
                                                          const float* __restrict__ Ap,
                                                          const float* __restrict__ Wt,
                                                          float* __restrict__ WtOut, float* Dt, int nwg,
-                                                         u64* granules, int* timeout_flag, long long spin_limit) {
+                                                         u64* granules, int* timeout_flag, long long spin_limit,
+                                                         int j_begin, int j_end) {
+    // atoms j_begin .. j_end-1 (multiples of the panel width): a later launch goes on where an earlier
+    // one stopped - all it needs of the earlier atoms are their deltas in Dt (the left-looking update
+    // reads them from memory anyway)
     // nwg > 1: workgroup g owns rows g * 256 RPT .. (g + 1) * 256 RPT - 1 and the workgroups exchange
     // their parts of every atom's squared norm (below); everything else is per row.
     constexpr int PW = 16;
@@ -192,7 +196,7 @@ __global__ __launch_bounds__(256) void dict_panel_kernel(int d, int r, int lda,
     }
     const int voffA = (g4 * lda + c16) * 4;
 
-    for (int j0 = 0; j0 < r; j0 += PW) {
+    for (int j0 = j_begin; j0 < j_end; j0 += PW) {
         float q[RPT][PW], w[RPT][PW];
         // this panel's entries of Q0 - B (formed by the product's epilogue) and of W
 #pragma unroll
@@ -373,18 +377,22 @@ __global__ void zero_u64_kernel(u64* p, size_t n) {
 
 }  // namespace
 
+bool dict_pass_splits(const onmf_ctx* c, int d, int r) { return d <= 16 * 1024 && c->dict_kernel != 1 && r >= 32; }
+
 int launch_dict_pass(onmf_ctx* c, int d, int r, const float* Win, const float* A, const float* B,
-                     float* Wout, hipStream_t s) {
-    c->dict_coop_last = false;
+                     float* Wout, hipStream_t s, int part) {
+    if (part != 0 && !dict_pass_splits(c, d, r))
+        return onmf_fail(c, ONMF_ERR_ARG, "update_dict: this shape is not taken in two parts");
+    if (part != 2) c->dict_coop_last = false;
     if (d <= 16 * 1024 && c->dict_kernel != 1) {
         // one workgroup per 1024 rows; several exchange the atoms' norms (they are few: co-resident)
         const int nwg = (d + 1023) / 1024;
         const int lda = (r + 15) / 16 * 16;
-        // Qt0[j][i] = sum_k A[k][j] * W[i][k]
+        // part 1: atoms before the middle panel boundary, part 2: the rest, part 0: all
+        const int jmid = (lda / 16 / 2) * 16;
+        const int j_begin = part == 2 ? jmid : 0, j_end = part == 1 ? jmid : lda;
         ONMF_TRY(onmf_reserve(c, c->qt, (size_t)r * d * sizeof(float), "dictionary Qt"));
         float* Qt = (float*)c->qt.p;
-        ONMF_TRY(launch_gemm(c, /*a_km=*/true, /*b_kn=*/false, r, d, r, A, r, Win, r, 1.f, -1.f, B,
-                             Qt, d, s, &c->slab_side, /*no_split=*/true));   // Qt = A^T W^T - B
         ONMF_TRY(onmf_reserve(c, c->ddelta, (3 * (size_t)d * r + (size_t)r * lda + 16) * sizeof(float),
                               "dictionary deltas"));
         float* Ap = (float*)c->ddelta.p;             // 64-byte aligned rows
@@ -399,26 +407,34 @@ int launch_dict_pass(onmf_ctx* c, int d, int r, const float* Win, const float* A
             gran = (u64*)c->sync.p;
             c->dict_flag_off = ngran * sizeof(u64);
             flag = (int*)((char*)c->sync.p + c->dict_flag_off);
-            hipLaunchKernelGGL(zero_u64_kernel, dim3((unsigned)((ngran + 8 + 255) / 256)), dim3(256), 0, s, gran,
-                               ngran + 8);
-            HIP_TRY(c, hipGetLastError());
+            if (part != 2) {
+                hipLaunchKernelGGL(zero_u64_kernel, dim3((unsigned)((ngran + 8 + 255) / 256)), dim3(256), 0, s, gran,
+                                   ngran + 8);
+                HIP_TRY(c, hipGetLastError());
+            }
             c->dict_coop_last = true;
         }
-        ONMF_TRY(launch_transpose(d, r, Win, Wt, s));
-        hipLaunchKernelGGL(dict_pad_kernel, dim3(r), dim3(64), 0, s, r, lda, A, Ap);
-        HIP_TRY(c, hipGetLastError());
+        if (part != 2) {
+            // Qt0[j][i] = sum_k A[k][j] * W[i][k] - B[j][i]
+            ONMF_TRY(launch_gemm(c, /*a_km=*/true, /*b_kn=*/false, r, d, r, A, r, Win, r, 1.f, -1.f, B,
+                                 Qt, d, s, &c->slab_side, /*no_split=*/true));
+            ONMF_TRY(launch_transpose(d, r, Win, Wt, s));
+            hipLaunchKernelGGL(dict_pad_kernel, dim3(r), dim3(64), 0, s, r, lda, A, Ap);
+            HIP_TRY(c, hipGetLastError());
+        }
         // 256 threads, thread t owns rows t, t + 256, ... of its workgroup's 1024
         const int rpt = nwg > 1 ? 4 : (d + 255) / 256;
         const int nt = rpt > 1 ? 256 : (d + 63) / 64 * 64;
         const long long spin_limit = 200000000LL;   // 2 s of the 100 MHz wall clock
 #define PANEL_CASE(RPTV)                                                                              \
     hipLaunchKernelGGL((dict_panel_kernel<RPTV>), dim3(nwg), dim3(nt), 0, s, d, r, lda, Qt, Ap, Wt, WtOut, Dt, \
-                       nwg, gran, flag, spin_limit)
+                       nwg, gran, flag, spin_limit, j_begin, j_end)
         if (rpt <= 1) PANEL_CASE(1);
         else if (rpt <= 2) PANEL_CASE(2);
         else PANEL_CASE(4);
 #undef PANEL_CASE
         HIP_TRY(c, hipGetLastError());
+        if (part == 1) return ONMF_OK;
         return launch_transpose(r, d, WtOut, Wout, s);
     }
     if (c->dict_kernel == 2)

@@ -244,6 +244,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmParams p) {
     for (int t = 0; t < ntiles; t += 2) {
         round(t, ra, rb, ra2, rb2);
         if (t + 1 < ntiles) round(t + 1, ra2, rb2, ra, rb);
+        // the accumulators stay in the accumulation registers across the loop edge (left alone, the
+        // compiler carries them through vector registers: 128 copies per trip)
+        asm volatile("" : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[1][0]), "+a"(acc[1][1]));
     }
 
     // accumulator element e of lane l: row (e&3) + 8*(e>>2) + 4*(l>>5), column l&31
@@ -334,8 +337,11 @@ int launch_gemm(onmf_ctx* c, bool a_km, bool b_kn, int M, int N, int K, const fl
     const int ktiles = (K + BK - 1) / BK;
     int splits = 1;
     if (tiles < 256 && ktiles >= 4 && !no_split) {
-        // few tiles: one workgroup per CU is enough, and half as many slabs for the reduction to read
-        splits = ((tiles <= 4 ? 256 : 512) + tiles - 1) / tiles;
+        // few tiles: one workgroup per CU is enough, and half as many slabs for the reduction to read;
+        // otherwise a little under two per CU, so that the launch is still ONE round of workgroups when
+        // a small kernel on another stream holds a few of the chip's slots (with exactly two per CU a
+        // single missing slot leaves one workgroup for a second round: up to twice the time)
+        splits = (tiles <= 4 ? 256 + tiles - 1 : 480) / tiles;
         const int max_by_k = ktiles / 2;          // at least 2 k-tiles of work per slab
         if (splits > max_by_k) splits = max_by_k;
         if (splits < 1) splits = 1;

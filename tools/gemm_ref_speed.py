@@ -35,3 +35,4 @@ eng = get_engine()
 A0 = torch.zeros(r, r, device=dev)
 B0 = torch.zeros(r, d, device=dev)
 timeit(lambda: eng.aggregate(X, H, 0.5, A0, B0), 2.0 * d * r * b + 2.0 * r * r * b, "library H X^T + H H^T")
+timeit(lambda: eng.sparse_code(X, W, H0=H, sub_iter=0), 2.0 * d * r * b + 2.0 * d * r * r, "library W^T X + W^T W")
