@@ -377,7 +377,25 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
             prep_rc = launch_fill_uniform(buf[0], rb, seed, ps);
         }
     }
-    const int cm_rc = launch_gemm(c, true, true, r, b, d, W, r, X, ldx, 1.f, 0.f, nullptr, Cm, b, s);
+    const double tol = (double)stopping_diff;
+    const double rank_cap = (double)std::min(r, b);
+    const int exact_cd = (coder_mode == ONMF_CODER_EXACT_CD);
+    const bool screened = !exact_cd && tol >= 0.0 && !c->exact_stop && c->screen_stop &&
+                          c->sweep_kernel != 1 && sweep_tile_covers(r, b) &&
+                          sub_iter <= SCREEN_MAX_SWEEPS && keep_sweeping(1.0, tol);
+    int init_rc = ONMF_OK;
+    const bool probes_new = c->screen_r != r;     // (the set-up below records r)
+    if (screened) {
+        // The screen's set-up goes in FRONT of the big product: it is needed before the sweeps anyway,
+        // and the few microseconds it takes let the small kernels on the other streams (Gm, the start
+        // code, the head of the dictionary pass) take their places on the chip before the product's
+        // workgroups fill it - behind them they would wait for its first round to finish.
+        init_rc = onmf_reserve(c, c->screen, (size_t)ScreenLayout::TOTAL * sizeof(float), "stop-test screen");
+        if (init_rc == ONMF_OK) init_rc = launch_screen_init(c, (float*)c->screen.p, r, s);
+    }
+    const int cm_rc = init_rc != ONMF_OK
+                          ? init_rc
+                          : launch_gemm(c, true, true, r, b, d, W, r, X, ldx, 1.f, 0.f, nullptr, Cm, b, s);
     if (ps != s) {                       // always rejoin, also on an error path
         hipError_t e1 = hipEventRecord(c->ev_prep_join, ps);
         hipError_t e2 = hipStreamWaitEvent(s, c->ev_prep_join, 0);
@@ -388,23 +406,15 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
     }
     ONMF_TRY(prep_rc);
     ONMF_TRY(cm_rc);
-    const double tol = (double)stopping_diff;
-    const double rank_cap = (double)std::min(r, b);
-    const int exact_cd = (coder_mode == ONMF_CODER_EXACT_CD);
     const double nan = std::numeric_limits<double>::quiet_NaN();
     int done = 0;
 
-    const bool screened = !exact_cd && tol >= 0.0 && !c->exact_stop && c->screen_stop &&
-                          c->sweep_kernel != 1 && sweep_tile_covers(r, b) &&
-                          sub_iter <= SCREEN_MAX_SWEEPS && keep_sweeping(1.0, tol);
     if (screened) {
         // All sweeps are enqueued without host round trips - as ONE launch that runs them all when
         // the grid is resident as a whole (one workgroup per CU), else one launch per sweep; they
         // evaluate the stopping test themselves (two sweeps back) and end when it says so.
-        ONMF_TRY(onmf_reserve(c, c->screen, (size_t)ScreenLayout::TOTAL * sizeof(float), "stop-test screen"));
         float* base = (float*)c->screen.p;
-        const bool refresh_probes = c->screen_refresh_due || c->screen_r != r;
-        ONMF_TRY(launch_screen_init(c, base, r, s));
+        const bool refresh_probes = c->screen_refresh_due || probes_new;
         double min_margin = 1e300;       // smallest (lower bound / tol) among the "continue" verdicts
         bool undecided = false, posted = false;
         if (c->cu_count == 0) {

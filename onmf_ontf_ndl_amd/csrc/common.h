@@ -274,8 +274,8 @@ int launch_screen_refresh(onmf_ctx* c, float* base, int r, int b, const float* H
 // stored as that sweep's bound, and one power step of the vector it uses
 int launch_screen_cw(onmf_ctx* c, float* base, int r, int b, const float* H, int k, hipStream_t s);
 
-// part 0: the whole pass.  Parts 1 and 2 (dict_pass_splits): the atoms before / from the middle panel
-// boundary, as two launches with the same arguments; W_out is complete after part 2.
+// part 0: the whole pass.  Parts 1 and 2 (dict_pass_splits): the first panels of atoms / the rest,
+// as two launches with the same arguments; W_out is complete after part 2.
 int launch_dict_pass(onmf_ctx* c, int d, int r, const float* Win, const float* A, const float* B,
                      float* Wout, hipStream_t s, int part = 0);
 bool dict_pass_splits(const onmf_ctx* c, int d, int r);

@@ -16,6 +16,8 @@
 // norm costs an LDS round and a barrier; it occupies a single CU and is several times faster.
 #include "common.h"
 
+#include <algorithm>
+
 namespace {
 
 typedef unsigned long long u64;
@@ -389,7 +391,9 @@ int launch_dict_pass(onmf_ctx* c, int d, int r, const float* Win, const float* A
         const int nwg = (d + 1023) / 1024;
         const int lda = (r + 15) / 16 * 16;
         // part 1: atoms before the middle panel boundary, part 2: the rest, part 0: all
-        const int jmid = (lda / 16 / 2) * 16;
+        // (measured at d=1024, r=256: 3/8 - 5/8 leaves the second part longer than the products it runs
+        // beside)
+        const int jmid = std::max(1, lda / 16 / 2) * 16;
         const int j_begin = part == 2 ? jmid : 0, j_end = part == 1 ? jmid : lda;
         ONMF_TRY(onmf_reserve(c, c->qt, (size_t)r * d * sizeof(float), "dictionary Qt"));
         float* Qt = (float*)c->qt.p;
