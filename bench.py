@@ -100,6 +100,8 @@ def main():
     ap.add_argument("--sync-every", type=int, default=4, help="steps between (A,B,W) all-reduces at N>1")
     ap.add_argument("--batches", type=int, default=3, help="distinct resident batches cycled through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true",
+                    help="skip the short extra measurement of the r = 64 case that is reported under 'also'")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
                     help="library option (ONMF_OPT_* number = value), for experiments")
     ap.add_argument("--cpu-cols", type=int, default=0, help="columns of the CPU-baseline sample (0 = auto)")
@@ -194,6 +196,25 @@ def main():
                                "traffic": measured_traffic(d, r, b, sweeps_per_launch),
                                "avg_launch_ms": avg_ms, "launches": sweep_launches,
                                "sweeps_per_launch": sweeps_per_launch}
+        if world == 1 and args.workload == "headline" and not args.no_also:
+            # the small reference-scale case (d=1024, r=64, batch=8192) beside the headline number: it is
+            # bound by launches and the host's part in borderline stopping tests, not by the kernels
+            d2, r2, b2 = WORKLOADS["c2"]
+            X2 = torch.rand(d2, b2, device=eng.device, generator=gen)
+            W2 = eng.update_dict(torch.rand(d2, r2, device=eng.device, generator=gw), eng.zeros(r2, r2), eng.zeros(r2, d2))
+            A2, B2 = eng.zeros(r2, r2), eng.zeros(r2, d2)
+            t2 = 1
+            for i in range(25):
+                if i == 5:
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                _, A2, B2, _, W2, _, _ = eng.step(X2, A2, B2, None, W2, 1.0 / t2, alpha=0.0, H0=None, seed=t2,
+                                                  sub_iter=SWEEPS, stopping_diff=args.stopping_diff, want_code=False)
+                t2 += 1
+            torch.cuda.synchronize()
+            el2 = time.perf_counter() - t0
+            out["also"] = {"workload": "c2: d=%d r=%d batch=%d, same settings, 20 steps after 5" % (d2, r2, b2),
+                           "ms_per_step": 1e3 * el2 / 20, "value": b2 * 20 / el2, "unit": "patches/s"}
         if not args.no_cpu_baseline:
             cols = args.cpu_cols or min(b, 4096)
             out["cpu_baseline"] = cpu_baseline(d, r, cols)
