@@ -451,7 +451,9 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
                                          (float)rank_cap, s));
             HIP_TRY(c, hipMemcpyAsync(c->pinned, base + ScreenLayout::REC,
                                       (size_t)4 * SCREEN_MAX_SWEEPS * sizeof(float), hipMemcpyDeviceToHost, s));
-            if (after && start == 0 && (rb & 3) == 0) {
+            // (not when the previous solve needed the host: chances are this one does too, and the work
+            // enqueued here would run twice)
+            if (after && start == 0 && (rb & 3) == 0 && !c->screen_last_undecided) {
                 // the host waits for the records only; the follow-up work is already behind them
                 if (!c->ev_rec) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_rec, hipEventDisableTiming));
                 HIP_TRY(c, hipEventRecord(c->ev_rec, s));
@@ -513,6 +515,7 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
         }
         // the next solve refreshes its probes if these left the bounds undecided or close to it
         c->screen_refresh_due = undecided || min_margin < 1.5;
+        c->screen_last_undecided = undecided;
         if (posted && !undecided) {      // the device put the result in H and the follow-up work stands
             if (after_valid) *after_valid = true;
             if (sweeps_done) *sweeps_done = done;
