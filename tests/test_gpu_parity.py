@@ -405,3 +405,56 @@ def test_size_independent_properties_at_scale(eng):
     # dictionary pass keeps the constraint set: nonnegative, column norms <= 1
     W1 = eng.update_dict(W, A1, B1)
     assert float(W1.min()) >= 0 and float(torch.linalg.norm(W1, dim=0).max()) <= 1 + 1e-5
+
+
+def test_step_with_a_tall_dictionary_against_oracle(eng, orc):
+    """d > 1024: the dictionary pass runs on several workgroups that exchange the atoms' norms, and in
+    two parts around the code solve."""
+    d, r, b = 2100, 40, 300
+    rs = np.random.RandomState(d + r + b)
+    X = rs.rand(d, b)
+    W = rs.rand(d, r)
+    W /= np.maximum(1, np.linalg.norm(W, axis=0))
+    Hw = rs.rand(r, b)
+    A = Hw @ Hw.T / 300
+    B = Hw @ X.T / 300
+    H0 = rs.rand(r, b)
+    tr = []
+    H_o, agg_o, W_o, _ = orc.minibatch_step(X, [A, B], W, 4, H0=H0, trace=tr, norm="gram")
+    H, A1, B1, _, W1, sweeps, _ = eng.step(eng.dev(X), eng.dev(A), eng.dev(B), None, eng.dev(W), 0.25, H0=eng.dev(H0))
+    assert sweeps == len(tr)
+    assert relerr(host(H), H_o) < TOL_H
+    assert relerr(host(A1), agg_o[0]) < TOL_AGG and relerr(host(B1), agg_o[1]) < TOL_AGG
+    assert relerr(host(W1), W_o) < TOL_W
+
+
+def test_full_size_step_equals_its_parts(eng):
+    """d = 1024, r = 256, b = 65536 (the headline shape): one step call - all sweeps in one launch,
+    dictionary pass in two parts beside the products - gives bit for bit what the three entry points give
+    one after the other, and the results have the properties the domain demands."""
+    import torch
+    d, r, b = 1024, 256, 65536
+    g = torch.Generator(device=eng.device).manual_seed(99)
+    X = torch.rand(d, b, device=eng.device, generator=g)
+    W = torch.rand(d, r, device=eng.device, generator=g)
+    W = W / torch.clamp(torch.linalg.norm(W, dim=0), min=1.0)
+    H0 = torch.rand(r, b, device=eng.device, generator=g)
+    Hw = torch.rand(r, 512, device=eng.device, generator=g)
+    A = Hw @ Hw.t() / 512
+    B = Hw @ torch.rand(d, 512, device=eng.device, generator=g).t() / 512
+    H1, A1, B1, _, W1, sweeps, _ = eng.step(X, A, B, None, W, 0.2, H0=H0)
+    H2, sweeps2, _ = eng.sparse_code(X, W, H0=H0, alpha=0.0, sub_iter=10, stopping_diff=0.01)
+    A2, B2, _ = eng.aggregate(X, H2, 0.2, A, B)
+    W2 = eng.update_dict(W, A, B)                      # the OLD aggregates (src/onmf.py:161)
+    assert sweeps == sweeps2
+    assert torch.equal(H1, H2) and torch.equal(A1, A2) and torch.equal(B1, B2) and torch.equal(W1, W2)
+    assert float(H1.min()) >= 0
+    assert float((A1 - A1.t()).abs().max()) == 0.0
+    assert float(W1.min()) >= 0 and float(torch.linalg.norm(W1, dim=0).max()) <= 1 + 1e-5
+    # columns are independent: a slice coded alone agrees to rounding (its W^T X is summed in another
+    # order - a few-tile product is split over k - and ten sweeps at r = 256 amplify those last bits)
+    Hs, _, _ = eng.sparse_code(X[:, 4096:4352].contiguous(), W, H0=H0[:, 4096:4352].contiguous(), alpha=0.0,
+                               sub_iter=sweeps, stopping_diff=-1.0)
+    assert relerr(host(Hs), host(H1[:, 4096:4352])) < 1e-4
+    # each sweep descends on 0.5 * ||X - W H||^2
+    assert float(torch.linalg.norm(X - W @ H1)) < float(torch.linalg.norm(X - W @ H0))
