@@ -236,6 +236,10 @@ double onmf_host_lambda_max(const float* S_host, int n);
  *   ONMF_OPT_PERSISTENT_SWEEPS != 0 (default): with the screened stopping test, run all sweeps of
  *                          a solve in one launch when its grid (one workgroup per 256 columns)
  *                          fits the chip's CUs; 0: one launch per sweep.
+ *   ONMF_OPT_SPIN_LIMIT_MS bound, in milliseconds, of the waits of a one-launch solve's workgroups for each
+ *                          other (default 2000; negative: give up at the first look, which exercises
+ *                          the recovery path - every kernel still ends normally).  After a timeout the
+ *                          solve is run again with one launch per sweep, and so are all later ones.
  */
 #define ONMF_OPT_PROFILE 1
 #define ONMF_OPT_EXACT_STOP 2
@@ -244,6 +248,7 @@ double onmf_host_lambda_max(const float* S_host, int n);
 #define ONMF_OPT_SCREEN_STOP 5
 #define ONMF_OPT_DICT_KERNEL 6
 #define ONMF_OPT_PERSISTENT_SWEEPS 7
+#define ONMF_OPT_SPIN_LIMIT_MS 8
 int onmf_set_option(onmf_ctx* ctx, int key, int value);
 /* Summed device time (ms) and number of sweep-kernel launches since the previous call. */
 int onmf_get_profile(onmf_ctx* ctx, double* sweep_ms, int* sweep_launches);

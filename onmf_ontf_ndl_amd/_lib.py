@@ -22,6 +22,7 @@ OPT_OVERLAP_DICT = 4
 OPT_SCREEN_STOP = 5
 OPT_DICT_KERNEL = 6
 OPT_PERSISTENT_SWEEPS = 7
+OPT_SPIN_LIMIT_MS = 8
 NDL_GLAUBER = 0
 NDL_PIVOT = 1
 

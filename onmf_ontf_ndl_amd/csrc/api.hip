@@ -243,6 +243,9 @@ int onmf_set_option(onmf_ctx* c, int key, int value) {
         case ONMF_OPT_SCREEN_STOP: c->screen_stop = value; return ONMF_OK;
         case ONMF_OPT_DICT_KERNEL: c->dict_kernel = value; return ONMF_OK;
         case ONMF_OPT_PERSISTENT_SWEEPS: c->persistent_sweeps = value; return ONMF_OK;
+        case ONMF_OPT_SPIN_LIMIT_MS:
+            c->spin_limit = value < 0 ? -1LL : (long long)value * 100000LL;      // 100 MHz ticks
+            return ONMF_OK;
         default: return onmf_fail(c, ONMF_ERR_ARG, "onmf_set_option: unknown key %d", key);
     }
 }
@@ -325,7 +328,8 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
                             const float* W, const float* H0, uint64_t seed, float alpha,
                             int sub_iter, float stopping_diff, int coder_mode, float* H,
                             int* sweeps_done, float* dist_trace, hipStream_t s,
-                            const std::function<int()>* after = nullptr, bool* after_valid = nullptr) {
+                            const std::function<int()>* after = nullptr, bool* after_valid = nullptr,
+                            bool second_try = false) {
     // `after`: work that consumes H (the step's aggregate products).  When the solve is enqueued as a
     // whole, it is enqueued too BEFORE the host waits for the verdicts, so the GPU does not idle
     // through that round trip; *after_valid tells the caller whether that run stands (it does not if
@@ -425,7 +429,7 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
         const bool persistent = c->persistent_sweeps && sweep_tile_workgroups(b) <= c->cu_count;
         int start = 0;
         while (start < sub_iter) {
-            const ScreenDev sc = {base, start, (float)tol, (float)rank_cap, 200000000LL /* 2 s */};
+            const ScreenDev sc = {base, start, (float)tol, (float)rank_cap, c->spin_limit /* 2 s */};
             int i = start;
             // When the probes are due for a power step, it is taken on the move of the SECOND sweep (the
             // first one is the jump away from the random start; the later moves resemble each other
@@ -472,8 +476,14 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
                 if (code == 0) {
                     HIP_TRY(c, hipMemcpy(&done, base + ScreenLayout::FLAG, sizeof(int), hipMemcpyDeviceToHost));
                     if (done == SCREEN_FLAG_TIMEOUT) {
-                        // the grid was not resident as a whole (CUs taken or masked): do not try again
+                        // the grid was not resident as a whole (CUs taken or masked): from now on one launch
+                        // per sweep, which needs no co-residency - starting with this very solve, if its
+                        // start can be had again (drawn from the seed, or still in the caller's H0)
                         c->persistent_sweeps = 0;
+                        const bool start_intact = H0 == nullptr || (H0 != buf[0] && H0 != buf[1] && H0 != buf[2]);
+                        if (!second_try && start_intact)
+                            return sparse_code_impl(c, d, r, b, X, ldx, W, H0, seed, alpha, sub_iter, stopping_diff,
+                                                    coder_mode, H, sweeps_done, dist_trace, s, after, after_valid, true);
                         return onmf_fail(c, ONMF_ERR_TIMEOUT,
                                          "sparse_code: a sweep workgroup waited more than 2 s for the others; "
                                          "later solves use one launch per sweep");

@@ -56,6 +56,7 @@ struct onmf_ctx {
     int screen_r = -1;              // r of the probes currently held in `screen`
     bool screen_refresh_due = true; // the next screened solve runs a probe power step
     bool screen_last_undecided = false;   // the last screened solve needed the host for a verdict
+    long long spin_limit = 200000000LL;   // bound of the sweeps' waits for each other, 100 MHz ticks (2 s)
     int persistent_sweeps = 1;      // all sweeps of a screened solve in one launch when the grid fits the chip
     int cu_count = 0;
     DevBuf ddelta;                  // dictionary pass: atom deltas (d x r), one-workgroup kernel

@@ -147,3 +147,29 @@ def test_one_launch_for_all_sweeps_equals_one_launch_per_sweep(eng, d, r, b, tol
     for key, (H, s, _) in out.items():
         assert s == se, key
         assert torch.equal(H, He), key
+
+
+def test_a_timed_out_one_launch_solve_is_redone_launch_by_launch(eng):
+    """The waits of a one-launch solve are given no time at all: whichever workgroup finds the others'
+    sums incomplete at its first look gives up (every kernel still ends normally).  The library then
+    runs the same solve with one launch per sweep; the caller sees the ordinary result."""
+    import torch
+    g = torch.Generator(device=eng.device).manual_seed(42)
+    d, r, b = 128, 48, 40000                       # 157 workgroups
+    X = torch.rand(d, b, device=eng.device, generator=g)
+    W = torch.rand(d, r, device=eng.device, generator=g)
+    W = W / torch.clamp(torch.linalg.norm(W, dim=0), min=1.0)
+    H0 = torch.rand(r, b, device=eng.device, generator=g)
+    eng.set_option(PERSISTENT, 0)
+    ref = eng.sparse_code(X, W, H0=H0, stopping_diff=0.01)
+    eng.set_option(PERSISTENT, 1)
+    eng.set_option(8, -1)
+    try:
+        got = eng.sparse_code(X, W, H0=H0, stopping_diff=0.01)
+        again = eng.sparse_code(X, W, H0=H0, stopping_diff=0.01)
+    finally:
+        eng.set_option(8, 2000)
+        eng.set_option(PERSISTENT, 1)
+    for out in (got, again):
+        assert out[1] == ref[1]
+        assert torch.equal(out[0], ref[0])
