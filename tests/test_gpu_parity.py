@@ -458,3 +458,23 @@ def test_full_size_step_equals_its_parts(eng):
     assert relerr(host(Hs), host(H1[:, 4096:4352])) < 1e-4
     # each sweep descends on 0.5 * ||X - W H||^2
     assert float(torch.linalg.norm(X - W @ H1)) < float(torch.linalg.norm(X - W @ H0))
+
+
+def test_sixty_step_stream_stays_within_the_dictionary_tolerance(eng, orc):
+    """The bar of the task is on the LEARNED dictionary: 60 chained steps on fresh random batches
+    (d = 100, r = 16, b = 1000, state carried on the GPU in fp32) against the fp64 oracle on the same
+    stream - same sweep counts at every step, W within 1e-4 at the end (measured: 4e-6)."""
+    d, r, b = 100, 16, 1000
+    rs = np.random.RandomState(5)
+    W = rs.rand(d, r)
+    A, B = np.zeros((r, r)), np.zeros((r, d))
+    Wd, Ad, Bd = eng.dev(W), eng.dev(A), eng.dev(B)
+    for t in range(1, 61):
+        X = rs.rand(d, b)
+        H0 = rs.rand(r, b)
+        tr = []
+        _, (A, B), W, _ = orc.minibatch_step(X, [A, B], W, t, H0=H0, trace=tr, norm="gram")
+        _, Ad, Bd, _, Wd, sweeps, _ = eng.step(eng.dev(X), Ad, Bd, None, Wd, 1.0 / t, H0=eng.dev(H0))
+        assert sweeps == len(tr), t
+    assert relerr(host(Wd), W) < TOL_W
+    assert relerr(host(Ad), A) < TOL_AGG and relerr(host(Bd), B) < TOL_AGG
