@@ -605,8 +605,8 @@ static int aggregate_impl(onmf_ctx* c, int d, int r, int b, const float* X, int 
     HIP_TRY(c, hipSetDevice(c->device));
     const float fw = (float)w, keep = (float)(1.0 - w);
     // A_out = (1-w) A_in + w H H^T ; B_out = (1-w) B_in + w H X^T   (src/onmf.py:155-156)
-    ONMF_TRY(launch_gemm(c, false, false, r, r, b, H, b, H, b, fw, A_in ? keep : 0.f, A_in, A_out, r, s));
-    ONMF_TRY(launch_gemm(c, false, false, r, d, b, H, b, X, ldx, fw, B_in ? keep : 0.f, B_in, B_out, d, s));
+    ONMF_TRY(launch_gemm_nt_pair(c, r, b, H, b, H, b, r, X, ldx, d, fw, A_in ? keep : 0.f, A_in, A_out, r,
+                                 B_in ? keep : 0.f, B_in, B_out, d, s));
     if (C_out)   // C_out = (1-w) C_in + w X X^T   (src/onmf.py:158)
         ONMF_TRY(launch_gemm(c, false, false, d, d, b, X, ldx, X, ldx, fw, C_in ? keep : 0.f, C_in, C_out, d, s));
     return ONMF_OK;

@@ -164,6 +164,9 @@ __global__ __launch_bounds__(256) void dict_panel_kernel(int d, int r, int lda,
     // nwg > 1: workgroup g owns rows g * 256 RPT .. (g + 1) * 256 RPT - 1 and the workgroups exchange
     // their parts of every atom's squared norm (below); everything else is per row.
     constexpr int PW = 16;
+    // a latency chain that shares its CU with workgroups of the products running beside it: its
+    // instructions go first
+    __builtin_amdgcn_s_setprio(3);
     const int wg = blockIdx.x;
     const int row0 = wg * (RPT * 256);
     bool dead = false;                                        // gave up waiting for the other workgroups

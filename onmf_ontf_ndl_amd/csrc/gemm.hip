@@ -17,6 +17,8 @@
 // in a fixed order, so results are bitwise reproducible.
 #include "common.h"
 
+#include <algorithm>
+
 namespace {
 
 constexpr int BM = 128;
@@ -44,6 +46,10 @@ struct GemmParams {
     int tiles_n;
     int vecA, vecB;
     float alpha, beta;
+    // optional second B operand: output columns >= n1 (a multiple of BN) contract with B2 instead
+    // (two products that share A in one launch); n1 == 0: none
+    const float* B2;
+    int ldb2, n1, vecB2;
 };
 
 // Global -> registers for one BK x 128 operand tile (4 float4 per thread).
@@ -196,7 +202,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmParams p) {
     TileSource<A_KM> srcA;
     TileSource<B_KN> srcB;
     srcA.init(p.A, p.lda, p.M, p.K, m0, kbeg, kend, p.vecA);
-    srcB.init(p.B, p.ldb, p.N, p.K, n0, kbeg, kend, p.vecB);
+    if (p.n1 > 0 && n0 >= p.n1) srcB.init(p.B2, p.ldb2, p.N - p.n1, p.K, n0 - p.n1, kbeg, kend, p.vecB2);
+    else srcB.init(p.B, p.ldb, p.n1 > 0 ? p.n1 : p.N, p.K, n0, kbeg, kend, p.vecB);
     if (ntiles > 0) {
         srcA.load(0, ra);
         srcB.load(0, rb);
@@ -278,10 +285,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmParams p) {
 // four threads per output: thread group g adds slabs g, g+4, g+8, ... in order, the four partial sums
 // are added in order - a fixed summation order whatever the grid, so results are reproducible, and a
 // few outputs with many slabs (the small Gram matrices) still spread over the chip.
+// With n1 > 0 the columns from n1 on go to a second output (C2, ldc2) with their own beta2 * Cin2.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab,
                                                              int splits, int M, int N, float alpha,
                                                              float beta, const float* Cin,
-                                                             float* C, int ldc) {
+                                                             float* C, int ldc, int n1, float beta2,
+                                                             const float* Cin2, float* C2, int ldc2) {
     __shared__ float part[4][64];
     const size_t mn = (size_t)M * N;
     const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
@@ -296,8 +305,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
             const float t = ((part[0][o] + part[1][o]) + part[2][o]) + part[3][o];
             const int row = (int)(i / N), col = (int)(i % N);
             float v = alpha * t;
-            if (beta != 0.f) v += beta * Cin[(size_t)row * ldc + col];
-            C[(size_t)row * ldc + col] = v;
+            if (n1 > 0 && col >= n1) {
+                const size_t at = (size_t)row * ldc2 + (col - n1);
+                if (beta2 != 0.f) v += beta2 * Cin2[at];
+                C2[at] = v;
+            } else {
+                if (beta != 0.f) v += beta * Cin[(size_t)row * ldc + col];
+                C[(size_t)row * ldc + col] = v;
+            }
         }
         __syncthreads();
     }
@@ -331,6 +346,7 @@ int launch_gemm(onmf_ctx* c, bool a_km, bool b_kn, int M, int N, int K, const fl
     p.alpha = alpha; p.beta = beta;
     p.vecA = (((uintptr_t)A & 15) == 0 && (lda & 3) == 0) ? 1 : 0;
     p.vecB = (((uintptr_t)B & 15) == 0 && (ldb & 3) == 0) ? 1 : 0;
+    p.B2 = nullptr; p.ldb2 = 0; p.n1 = 0; p.vecB2 = 0;
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     p.tiles_n = tiles_n;
     const int tiles = tiles_m * tiles_n;
@@ -368,8 +384,49 @@ int launch_gemm(onmf_ctx* c, bool a_km, bool b_kn, int M, int N, int K, const fl
         int blocks = (int)((mn + 63) / 64);
         if (blocks > 4096) blocks = 4096;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, p.slab, splits, M, N,
-                           alpha, beta, Cin, C, ldc);
+                           alpha, beta, Cin, C, ldc, 0, 0.f, (const float*)nullptr, (float*)nullptr, 0);
         HIP_TRY(c, hipGetLastError());
     }
+    return ONMF_OK;
+}
+
+// C1 = beta1*Cin1 + alpha * A B1^T (M x N1) and C2 = beta2*Cin2 + alpha * A B2^T (M x N2) in ONE launch when
+// the shapes allow (A [m][k], B1 [n][k], B2 [n][k]; N1 a multiple of the tile width; a contraction
+// long enough to be split): one round of workgroups over both outputs and one reduction, instead of
+// two launches each with its own tail.  Otherwise two ordinary products.
+int launch_gemm_nt_pair(onmf_ctx* c, int M, int K, const float* A, int lda, const float* B1, int ldb1, int N1,
+                        const float* B2, int ldb2, int N2, float alpha, float beta1, const float* Cin1, float* C1,
+                        int ldc1, float beta2, const float* Cin2, float* C2, int ldc2, hipStream_t s) {
+    const int N = N1 + N2;
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    const int tiles = tiles_m * tiles_n;
+    const int ktiles = (K + BK - 1) / BK;
+    int splits = (tiles > 4 && tiles < 256 && ktiles >= 4) ? std::min(480 / tiles, ktiles / 2) : 1;
+    if ((N1 % BN) != 0 || splits < 2 || (beta1 != 0.f && !Cin1) || (beta2 != 0.f && !Cin2)) {
+        ONMF_TRY(launch_gemm(c, false, false, M, N1, K, A, lda, B1, ldb1, alpha, beta1, Cin1, C1, ldc1, s));
+        return launch_gemm(c, false, false, M, N2, K, A, lda, B2, ldb2, alpha, beta2, Cin2, C2, ldc2, s);
+    }
+    GemmParams p;
+    p.A = A; p.B = B1; p.Cin = Cin1; p.C = C1;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb1; p.ldc = ldc1;
+    p.alpha = alpha; p.beta = beta1;
+    p.vecA = (((uintptr_t)A & 15) == 0 && (lda & 3) == 0) ? 1 : 0;
+    p.vecB = (((uintptr_t)B1 & 15) == 0 && (ldb1 & 3) == 0) ? 1 : 0;
+    p.B2 = B2; p.ldb2 = ldb2; p.n1 = N1;
+    p.vecB2 = (((uintptr_t)B2 & 15) == 0 && (ldb2 & 3) == 0) ? 1 : 0;
+    p.tiles_n = tiles_n;
+    const int kt_per = (ktiles + splits - 1) / splits;
+    splits = (ktiles + kt_per - 1) / kt_per;
+    p.k_per_split = kt_per * BK;
+    p.splits = splits;
+    ONMF_TRY(onmf_reserve(c, c->slab, (size_t)splits * M * N * sizeof(float), "split-K slabs"));
+    p.slab = (float*)c->slab.p;
+    ONMF_TRY((run<false, false>(c, p, dim3(tiles, 1, splits), s)));
+    const size_t mn = (size_t)M * N;
+    int blocks = (int)((mn + 63) / 64);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, p.slab, splits, M, N, alpha, beta1, Cin1,
+                       C1, ldc1, N1, beta2, Cin2, C2, ldc2);
+    HIP_TRY(c, hipGetLastError());
     return ONMF_OK;
 }
