@@ -145,13 +145,16 @@ struct TileSource {
         soff0 = KMAJ ? (unsigned)(((size_t)kbeg * ld + x0) * 4) : (unsigned)(((size_t)x0 * ld + kbeg) * 4);
         sstep = KMAJ ? (unsigned)((size_t)BK * ld * 4) : (unsigned)(BK * 4);
     }
+    // NT: non-temporal loads - for an operand that is streamed (each element read by one or two
+    // workgroups), so that it does not push the small matrices other kernels work on out of the L2
+    template <bool NT = false>
     __device__ __forceinline__ void load(int tile, float4 (&rg)[4]) const {
         const int k0 = kbeg + tile * BK;
         if (fast && k0 + BK <= kend) {                       // uniform
             const unsigned so = soff0 + (unsigned)tile * sstep;
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
-                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff[p], so, 0);
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff[p], so, NT ? 2 : 0);
                 rg[p] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]),
                                     __uint_as_float(v[3]));
             }
@@ -206,12 +209,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmParams p) {
     else srcB.init(p.B, p.ldb, p.n1 > 0 ? p.n1 : p.N, p.K, n0, kbeg, kend, p.vecB);
     if (ntiles > 0) {
         srcA.load(0, ra);
-        srcB.load(0, rb);
+        srcB.template load<true>(0, rb);
         store_tile<A_KM>(As, ra);
         store_tile<B_KN>(Bs, rb);
         if (ntiles > 1) {
             srcA.load(1, ra);
-            srcB.load(1, rb);
+            srcB.template load<true>(1, rb);
         }
     }
     __syncthreads();
@@ -221,7 +224,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmParams p) {
         const int cur = t & 1;
         if (t + 2 < ntiles) {
             srcA.load(t + 2, ya);
-            srcB.load(t + 2, yb);
+            srcB.template load<true>(t + 2, yb);
         }
         const float* Ac = As + cur * A_STRIDE;
         const float* Bc = Bs + cur * B_STRIDE;
