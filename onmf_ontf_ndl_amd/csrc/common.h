@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -82,6 +83,23 @@ int onmf_reserve_pinned(onmf_ctx* c, size_t bytes);
         int _rc = (expr);                                                                       \
         if (_rc != ONMF_OK) return _rc;                                                         \
     } while (0)
+
+// A kernel that wants more than 64 KB of dynamic LDS must be told so once per device: the attribute
+// belongs to the current device's copy of the kernel, so the "already done" note is kept per device
+// (one static LdsLimit per kernel).  Relaxed atomics: two contexts on two threads may both set the
+// attribute, which is harmless.
+struct LdsLimit {
+    static constexpr int MAX_DEV = 64;
+    std::atomic<size_t> bytes[MAX_DEV];
+    LdsLimit() { for (auto& b : bytes) b.store(0, std::memory_order_relaxed); }
+};
+inline int onmf_raise_lds_limit(onmf_ctx* c, LdsLimit& lim, const void* kernel, size_t bytes) {
+    const bool slot = c->device >= 0 && c->device < LdsLimit::MAX_DEV;
+    if (slot && lim.bytes[c->device].load(std::memory_order_relaxed) >= bytes) return ONMF_OK;
+    HIP_TRY(c, hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    if (slot) lim.bytes[c->device].store(bytes, std::memory_order_relaxed);
+    return ONMF_OK;
+}
 
 // ---------------------------------------------------------------------------------------------
 // kernels' host launchers (defined in the .hip files)

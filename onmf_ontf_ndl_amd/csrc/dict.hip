@@ -468,12 +468,8 @@ int launch_dict_pass(onmf_ctx* c, int d, int r, const float* Win, const float* A
     hipLaunchKernelGGL(zero_u64_kernel, dim3((unsigned)((ngran + 8 + 255) / 256)), dim3(256), 0, s, gran,
                        ngran + 8);
     HIP_TRY(c, hipGetLastError());
-    static size_t attr_bytes = 0;
-    if (lds > attr_bytes) {
-        HIP_TRY(c, hipFuncSetAttribute((const void*)dict_pass_kernel,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_bytes = lds;
-    }
+    static LdsLimit lim;
+    ONMF_TRY(onmf_raise_lds_limit(c, lim, (const void*)dict_pass_kernel, lds));
     const long long spin_limit = 200000000LL;   // 2 s of the 100 MHz wall clock
     hipLaunchKernelGGL(dict_pass_kernel, dim3(nwg), dim3(64), lds, s, d, r, nwg, Qt, A, B, Win, Wout,
                        gran, flag, spin_limit);

@@ -324,12 +324,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 template <bool A_KM, bool B_KN>
 int run(onmf_ctx* c, const GemmParams& p, dim3 grid, hipStream_t s) {
     constexpr size_t bytes = sizeof(float) * 4 * TILE_ELEMS;
-    static bool attr_done = false;
-    if (!attr_done) {
-        HIP_TRY(c, hipFuncSetAttribute((const void*)gemm_f32_kernel<A_KM, B_KN>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-        attr_done = true;
-    }
+    static LdsLimit lim;
+    ONMF_TRY(onmf_raise_lds_limit(c, lim, (const void*)gemm_f32_kernel<A_KM, B_KN>, bytes));
     hipLaunchKernelGGL((gemm_f32_kernel<A_KM, B_KN>), grid, dim3(NTHREADS), bytes, s, p);
     HIP_TRY(c, hipGetLastError());
     return ONMF_OK;

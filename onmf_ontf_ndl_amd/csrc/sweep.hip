@@ -107,12 +107,8 @@ int launch_sweep_each(onmf_ctx* c, int r, int b, const float* Gm, const float* C
         return onmf_fail(c, ONMF_ERR_ARG, "sweep: the tile kernel covers r <= 256 (r=%d)", r);
     const size_t lds = (size_t)r * 64 * sizeof(float);
     if (lds > 160 * 1024) return onmf_fail(c, ONMF_ERR_ARG, "sweep: r=%d needs %zu B of LDS", r, lds);
-    static size_t attr_bytes = 0;
-    if (lds > attr_bytes) {
-        HIP_TRY(c, hipFuncSetAttribute((const void*)sweep_column_each_kernel,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_bytes = lds;
-    }
+    static LdsLimit lim;
+    ONMF_TRY(onmf_raise_lds_limit(c, lim, (const void*)sweep_column_each_kernel, lds));
     hipLaunchKernelGGL(sweep_column_each_kernel, dim3((b + 63) / 64), dim3(64), lds, s, r, b, Gm, Cm, H, alpha,
                        exact_cd, sub_iter, es);
     HIP_TRY(c, hipGetLastError());
@@ -124,12 +120,8 @@ static int launch_sweep_column(onmf_ctx* c, int r, int b, const float* Gm, const
                                double* stats, int* n_groups, hipStream_t s) {
     const size_t lds = (size_t)r * 64 * sizeof(float);
     if (lds > 160 * 1024) return onmf_fail(c, ONMF_ERR_ARG, "sweep: r=%d needs %zu B of LDS", r, lds);
-    static size_t attr_bytes = 0;
-    if (lds > attr_bytes) {
-        HIP_TRY(c, hipFuncSetAttribute((const void*)sweep_column_kernel,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_bytes = lds;
-    }
+    static LdsLimit lim;
+    ONMF_TRY(onmf_raise_lds_limit(c, lim, (const void*)sweep_column_kernel, lds));
     const int groups = (b + 63) / 64;
     *n_groups = groups;
     hipLaunchKernelGGL(sweep_column_kernel, dim3(groups), dim3(64), lds, s, r, b, Gm, Cm, Hin, Hout,

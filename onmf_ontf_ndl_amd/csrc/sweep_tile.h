@@ -500,12 +500,8 @@ int run_tile(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm, float*
     constexpr int NBLK = HALF ? NB * (NB + 1) / 2 : NB * NB;
     constexpr size_t lds = sizeof(float) * ((size_t)NBLK * 256 + 2 * NB * 16 + (PROBE ? (NB * 256 + 16 + 4 + 4) : 0));
     static_assert(lds <= 160 * 1024, "Gm blocks do not fit the LDS");
-    static bool attr_done = false;
-    if (!attr_done) {
-        HIP_TRY(c, hipFuncSetAttribute((const void*)sweep_tile_kernel<NB, HALF, PROBE, CT, EACH>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
-    }
+    static LdsLimit lim;
+    ONMF_TRY(onmf_raise_lds_limit(c, lim, (const void*)sweep_tile_kernel<NB, HALF, PROBE, CT, EACH>, lds));
     constexpr int NT = 1024 / CT;
     const int wgs = (b + TILE_COLS_PER_WG - 1) / TILE_COLS_PER_WG;
     *n_groups = wgs * (NT / 64);
