@@ -222,7 +222,7 @@ def main():
             el2 = time.perf_counter() - t0
             out["also"] = {"workload": "c2: d=%d r=%d batch=%d, same settings, 20 steps after 5" % (d2, r2, b2),
                            "ms_per_step": 1e3 * el2 / 20, "value": b2 * 20 / el2, "unit": "patches/s"}
-        if not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline:
             cols = args.cpu_cols or min(b, 4096)
             out["cpu_baseline"] = cpu_baseline(d, r, cols)
         print(json.dumps(out), flush=True)

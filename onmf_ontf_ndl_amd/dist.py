@@ -63,7 +63,9 @@ def average_state(W, A, B, group=None):
     td.all_reduce(flat, op=td.ReduceOp.SUM, group=group)
     flat /= td.get_world_size(group)
     W1, A1, B1 = unpack_state(flat, d, r)
-    return W1.contiguous(), A1.contiguous(), B1.contiguous()
+    # own allocations: slices of the packed vector start at odd offsets for odd r, and the kernels
+    # take their 16-byte paths only for 16-byte aligned matrices
+    return W1.clone(), A1.clone(), B1.clone()
 
 
 def allreduce_partial_aggregates(HHt, HXt, group=None):
