@@ -169,7 +169,8 @@ def main():
     sweep_ms, sweep_launches = eng.get_profile()
     eng.set_option(_lib.OPT_PROFILE, 0)
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=eng.device)
+        tt = torch.tensor([elapsed], dtype=torch.float64,
+                          device="cpu" if td.get_backend() == "gloo" else eng.device)
         td.all_reduce(tt, op=td.ReduceOp.MAX)
         elapsed = float(tt.item())
 

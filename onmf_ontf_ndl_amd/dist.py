@@ -11,7 +11,8 @@ H H^T and H X^T (src/onmf.py:155-156) and the replicated dictionary.  Two ways t
   and the partial sums are added before the (1-w, w) recursion - equal to the reference run on the
   concatenated batch up to summation order.
 
-Both helpers work on any tensor device: with the ``gloo`` backend hand them CPU tensors.
+Both helpers work on any tensor device; under the ``gloo`` backend device tensors are staged through
+host memory.
 """
 from __future__ import annotations
 
@@ -19,7 +20,10 @@ import os
 
 
 def init_from_env(backend=None):
-    """Initialise the default process group from RANK / WORLD_SIZE / MASTER_* if there is one."""
+    """Initialise the default process group from RANK / WORLD_SIZE / MASTER_* if there is one.
+
+    ``ONMF_DIST_BACKEND=gloo`` forces the host backend (e.g. to rehearse several ranks on a machine
+    with fewer GPUs than ranks: the local device index then wraps around the devices present)."""
     import torch
     import torch.distributed as td
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -30,13 +34,28 @@ def init_from_env(backend=None):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if not td.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("ONMF_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if backend != "nccl" and torch.cuda.is_available():
+            local %= max(1, torch.cuda.device_count())
         if backend == "nccl":
             torch.cuda.set_device(local)
             td.init_process_group(backend=backend, device_id=torch.device("cuda", local))
         else:
             td.init_process_group(backend=backend)
     return rank, world, local
+
+
+def all_reduce_sum(flat, group=None):
+    """In-place sum over the ranks.  A ``gloo`` group only ever sees host memory: a device tensor is
+    copied to the host (synchronously), reduced there and copied back."""
+    import torch.distributed as td
+    if flat.is_cuda and td.get_backend(group) == "gloo":
+        host = flat.cpu()
+        td.all_reduce(host, op=td.ReduceOp.SUM, group=group)
+        flat.copy_(host)
+    else:
+        td.all_reduce(flat, op=td.ReduceOp.SUM, group=group)
+    return flat
 
 
 def pack_state(W, A, B):
@@ -60,7 +79,7 @@ def average_state(W, A, B, group=None):
         return W, A, B
     d, r = W.shape
     flat = pack_state(W, A, B)
-    td.all_reduce(flat, op=td.ReduceOp.SUM, group=group)
+    all_reduce_sum(flat, group)
     flat /= td.get_world_size(group)
     W1, A1, B1 = unpack_state(flat, d, r)
     # own allocations: slices of the packed vector start at odd offsets for odd r, and the kernels
@@ -75,7 +94,7 @@ def allreduce_partial_aggregates(HHt, HXt, group=None):
     if not (td.is_available() and td.is_initialized()) or td.get_world_size(group) == 1:
         return HHt, HXt
     flat = torch.cat([HHt.reshape(-1), HXt.reshape(-1)])
-    td.all_reduce(flat, op=td.ReduceOp.SUM, group=group)
+    all_reduce_sum(flat, group)
     n = HHt.numel()
     HHt.copy_(flat[:n].reshape(HHt.shape))
     HXt.copy_(flat[n:].reshape(HXt.shape))
