@@ -329,11 +329,13 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
                             int sub_iter, float stopping_diff, int coder_mode, float* H,
                             int* sweeps_done, float* dist_trace, hipStream_t s,
                             const std::function<int()>* after = nullptr, bool* after_valid = nullptr,
-                            bool second_try = false) {
+                            bool second_try = false, const std::function<int()>* behind_sweeps = nullptr) {
     // `after`: work that consumes H (the step's aggregate products).  When the solve is enqueued as a
     // whole, it is enqueued too BEFORE the host waits for the verdicts, so the GPU does not idle
     // through that round trip; *after_valid tells the caller whether that run stands (it does not if
     // the host had to finish the solve: then the caller runs the work again).
+    // `behind_sweeps`: work that must not run beside the sweeps but needs nothing of them (the step's
+    // dictionary pass); it is posted right behind the last sweep launch, ahead of the verdict kernels.
     if (after_valid) *after_valid = false;
     if (d <= 0 || r <= 0 || b <= 0 || !X || !W || !H || ldx < b || sub_iter < 0)
         return onmf_fail(c, ONMF_ERR_ARG, "sparse_code: bad arguments (d=%d r=%d b=%d ldx=%d)", d, r, b, ldx);
@@ -370,7 +372,27 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
         HIP_TRY(c, hipEventRecord(c->ev_prep_fork, s));
         HIP_TRY(c, hipStreamWaitEvent(ps, c->ev_prep_fork, 0));
     }
-    int prep_rc = launch_gemm(c, true, true, r, r, d, W, r, W, r, 1.f, 0.f, nullptr, Gm, r, ps,
+    // Workgroups go to the chip's 32 shader engines (8 XCDs x 4) in turn, and a workgroup waits for a
+    // slot in ITS engine.  The big product's workgroups are whole rounds of the chip at the headline
+    // shape (2 x 512 tiles on 512 slots): a single slot held by another stream's workgroup - the
+    // dictionary pass - then costs it a further round, and that workgroup itself, arriving later, is
+    // placed only when the product's queue for its engine has drained, i.e. at the product's end,
+    // where it keeps a workgroup of the sweeps waiting.  So the main launch is given one workgroup
+    // fewer per engine (32 in all): its last round leaves a slot free in every engine, which is where
+    // the dictionary pass starts.  The columns taken off are computed at the head of the side stream,
+    // contraction split into many short workgroups, while the chip is still filling.
+    int tail_cols = 0;
+    {
+        const int tiles_m = (r + 127) / 128, tiles_n = (b + 127) / 128;
+        const int cols = 128 * std::max(1, 32 / tiles_m);
+        if (ps != s && tiles_m * tiles_n >= 512 && cols <= b / 4) tail_cols = cols;
+    }
+    int prep_rc = ONMF_OK;
+    if (tail_cols)
+        prep_rc = launch_gemm(c, true, true, r, tail_cols, d, W, r, X + (b - tail_cols), ldx, 1.f, 0.f, nullptr,
+                              Cm + (b - tail_cols), b, ps, &c->slab_prep);
+    if (prep_rc == ONMF_OK)
+        prep_rc = launch_gemm(c, true, true, r, r, d, W, r, W, r, 1.f, 0.f, nullptr, Gm, r, ps,
                               ps == s ? nullptr : &c->slab_prep);
     if (prep_rc == ONMF_OK) {
         if (H0) {
@@ -399,7 +421,7 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
     }
     const int cm_rc = init_rc != ONMF_OK
                           ? init_rc
-                          : launch_gemm(c, true, true, r, b, d, W, r, X, ldx, 1.f, 0.f, nullptr, Cm, b, s);
+                          : launch_gemm(c, true, true, r, b - tail_cols, d, W, r, X, ldx, 1.f, 0.f, nullptr, Cm, b, s);
     if (ps != s) {                       // always rejoin, also on an error path
         hipError_t e1 = hipEventRecord(c->ev_prep_join, ps);
         hipError_t e2 = hipStreamWaitEvent(s, c->ev_prep_join, 0);
@@ -450,6 +472,8 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
                     if (i < sub_iter) ONMF_TRY(launch_screen_cw(c, base, r, b, buf[i % 3], i, s));
                 }
             }
+            const bool ahead = after && start == 0 && (rb & 3) == 0 && !c->screen_last_undecided;
+            if (ahead && behind_sweeps) ONMF_TRY((*behind_sweeps)());
             // a sweep evaluates the test of the one two sweeps back: the last two are still open
             ONMF_TRY(launch_screen_final(c, base, std::max(start, sub_iter - 2), sub_iter - 1, (float)tol,
                                          (float)rank_cap, s));
@@ -457,7 +481,7 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
                                       (size_t)4 * SCREEN_MAX_SWEEPS * sizeof(float), hipMemcpyDeviceToHost, s));
             // (not when the previous solve needed the host: chances are this one does too, and the work
             // enqueued here would run twice)
-            if (after && start == 0 && (rb & 3) == 0 && !c->screen_last_undecided) {
+            if (ahead) {
                 // the host waits for the records only; the follow-up work is already behind them
                 if (!c->ev_rec) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_rec, hipEventDisableTiming));
                 HIP_TRY(c, hipEventRecord(c->ev_rec, s));
@@ -483,7 +507,8 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
                         const bool start_intact = H0 == nullptr || (H0 != buf[0] && H0 != buf[1] && H0 != buf[2]);
                         if (!second_try && start_intact)
                             return sparse_code_impl(c, d, r, b, X, ldx, W, H0, seed, alpha, sub_iter, stopping_diff,
-                                                    coder_mode, H, sweeps_done, dist_trace, s, after, after_valid, true);
+                                                    coder_mode, H, sweeps_done, dist_trace, s, after, after_valid, true,
+                                                    behind_sweeps);
                         return onmf_fail(c, ONMF_ERR_TIMEOUT,
                                          "sparse_code: a sweep workgroup waited more than 2 s for the others; "
                                          "later solves use one launch per sweep");
@@ -683,26 +708,31 @@ int onmf_step(onmf_ctx* c, int d, int r, int b, const float* X, int ldx, const f
         }
         HIP_TRY(c, hipEventRecord(c->ev_fork, s));
         HIP_TRY(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
-        // The pass is longer than the W^T X product it hides under, and while it holds a CU the sweeps
-        // (one workgroup per CU, all of them needed) cannot start.  It runs in two parts: the first half
-        // of the atoms beside W^T X, the second beside the aggregate products after the sweeps.
+        // The pass is one workgroup per 1024 rows that claims its CU whole, so it cannot run beside the
+        // sweeps (one workgroup per CU, all of them needed at once).  It runs in two parts: the first
+        // atoms beside W^T X, the rest beside the aggregate products - posted right behind the sweeps,
+        // ahead of the verdict kernels, so that its workgroup is resident before those products fill
+        // the chip (arriving after them it waits for one of their workgroups to end: most of their
+        // duration).
         const bool split = dict_pass_splits(c, d, r);
         int rc = launch_dict_pass(c, d, r, W_in, A_in, B_in, W_out, c->side, split ? 1 : 0);
         int rc2 = ONMF_OK;
         bool agg_done = false, second_posted = !split;
+        const std::function<int()> post_dict = [&]() {
+            if (second_posted) return (int)ONMF_OK;
+            second_posted = true;
+            if (!c->ev_mid) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_mid, hipEventDisableTiming));
+            HIP_TRY(c, hipEventRecord(c->ev_mid, s));                 // behind the sweeps
+            HIP_TRY(c, hipStreamWaitEvent(c->side, c->ev_mid, 0));
+            return launch_dict_pass(c, d, r, W_in, A_in, B_in, W_out, c->side, 2);
+        };
         const std::function<int()> agg = [&]() {
-            if (!second_posted) {
-                second_posted = true;
-                if (!c->ev_mid) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_mid, hipEventDisableTiming));
-                HIP_TRY(c, hipEventRecord(c->ev_mid, s));                 // behind the sweeps
-                HIP_TRY(c, hipStreamWaitEvent(c->side, c->ev_mid, 0));
-                ONMF_TRY(launch_dict_pass(c, d, r, W_in, A_in, B_in, W_out, c->side, 2));
-            }
+            ONMF_TRY(post_dict());
             return aggregate_impl(c, d, r, b, X, ldx, H, w, A_in, B_in, C_in, A_out, B_out, C_out, s);
         };
         if (rc == ONMF_OK)
             rc2 = sparse_code_impl(c, d, r, b, X, ldx, W_in, H0, seed, alpha, sub_iter, stopping_diff,
-                                   ONMF_CODER_DAMPED, H, sweeps_done, dist_trace, s, &agg, &agg_done);
+                                   ONMF_CODER_DAMPED, H, sweeps_done, dist_trace, s, &agg, &agg_done, false, &post_dict);
         if (rc == ONMF_OK && rc2 == ONMF_OK && !agg_done) rc2 = agg();
         hipError_t e1 = hipEventRecord(c->ev_join, c->side);
         // always rejoin, also on an error path, so the side stream never outlives the call's buffers

@@ -142,12 +142,142 @@ __device__ __forceinline__ float wave_sum_uniform(float x) {
 // Ap[k][0..lda) = A[k][0..r) followed by zeros, except the diagonal, which the pass never reads as
 // an entry of A: Ap[k][k] = -1 / (A[k][k] + 1), the (negated) step of atom k
 __global__ void dict_pad_kernel(int r, int lda, const float* __restrict__ A, float* __restrict__ Ap) {
+    __builtin_amdgcn_s_setprio(3);
     const int k = blockIdx.x;
     for (int j = threadIdx.x; j < lda; j += blockDim.x) {
         float v = j < r ? A[(size_t)k * r + j] : 0.f;
         if (j == k) v = -1.0f / (v + 1.0f);
         Ap[(size_t)k * lda + j] = v;
     }
+}
+
+// Everything the panel kernel reads, in ONE launch of many small workgroups (one dependent round
+// trip to memory each), because this is the head of a latency chain that runs beside a chip-filling
+// product of another stream, where every dependent memory access costs several times its usual time:
+//   Qt0[j][i] = sum_k A[k][j] W[i][k] - B[j][i]      (r x d; src/onmf.py:112 before any atom has moved)
+//   Wt[k][i]  = W[i][k]                              (r x d)
+//   Ap        = A padded to lda columns, diagonal replaced by -1 / (A[k][k] + 1)
+// A workgroup owns a tile of 32 atoms x 32 rows; per chunk of up to 256 k it stages A[k][J0..J0+31] and
+// W[I0..I0+31][k] (transposed) in LDS, 64 KB, and every thread accumulates 2 x 2 outputs.  The tiles
+// with J0 == 0 also write their rows of Wt, those with I0 == 0 their columns of Ap.
+constexpr int HEAD_T = 32, HEAD_KC = 256;
+__global__ __launch_bounds__(256) void dict_head_kernel(int d, int r, int lda, const float* __restrict__ A,
+                                                        const float* __restrict__ W, const float* __restrict__ B,
+                                                        float* __restrict__ Qt0, float* __restrict__ Wt,
+                                                        float* __restrict__ Ap) {
+    extern __shared__ __attribute__((aligned(16))) float hs[];
+    float* As = hs;                        // [HEAD_KC][32]  As[k][jj] = A[k0 + k][J0 + jj]
+    float* Ws = hs + HEAD_KC * HEAD_T;     // [HEAD_KC][32]  Ws[k][ii] = W[I0 + ii][k0 + k]
+    __builtin_amdgcn_s_setprio(3);
+    const int tid = threadIdx.x;
+    const int I0 = blockIdx.x * HEAD_T, J0 = blockIdx.y * HEAD_T;
+    const int tj = 2 * (tid >> 4), ti = 2 * (tid & 15);
+    // the tile's entries of B first: their latency passes under the staging
+    float bsub[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int j = J0 + tj + a, i = I0 + ti + c;
+            bsub[a][c] = (j < r && i < d) ? B[(size_t)j * d + i] : 0.f;
+        }
+    float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    const bool vecA = (r & 3) == 0 && (((uintptr_t)A) & 15) == 0;
+    const bool vecW = (r & 3) == 0 && (((uintptr_t)W) & 15) == 0;
+    for (int k0 = 0; k0 < r; k0 += HEAD_KC) {
+        const int kc = min(HEAD_KC, r - k0);
+        if (k0 > 0) __syncthreads();
+        // A panel: item = (k, float4 jq): rows of 128 B
+        {
+            float4 st[8];
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int item = tid + 256 * it, k = item >> 3, jq = item & 7;
+                const int j = J0 + 4 * jq;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k < kc) {
+                    const float* src = A + (size_t)(k0 + k) * r + j;
+                    if (vecA && j + 3 < r) {
+                        v = *reinterpret_cast<const float4*>(src);
+                    } else {
+                        if (j + 0 < r) v.x = src[0];
+                        if (j + 1 < r) v.y = src[1];
+                        if (j + 2 < r) v.z = src[2];
+                        if (j + 3 < r) v.w = src[3];
+                    }
+                }
+                st[it] = v;
+            }
+            // W panel: item = (ii, float4 kq) with ii fastest, so that the transposing LDS stores of a
+            // wave fall into 32 different banks
+            float4 sw[8];
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int item = tid + 256 * it, ii = item & 31, kq = item >> 5;
+                const int i = I0 + ii, k = 4 * kq;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i < d && k < kc) {
+                    const float* src = W + (size_t)i * r + k0 + k;
+                    if (vecW && k + 3 < kc) {
+                        v = *reinterpret_cast<const float4*>(src);
+                    } else {
+                        if (k + 0 < kc) v.x = src[0];
+                        if (k + 1 < kc) v.y = src[1];
+                        if (k + 2 < kc) v.z = src[2];
+                        if (k + 3 < kc) v.w = src[3];
+                    }
+                }
+                sw[it] = v;
+            }
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int item = tid + 256 * it, k = item >> 3, jq = item & 7;
+                *reinterpret_cast<float4*>(As + k * HEAD_T + 4 * jq) = st[it];
+            }
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int item = tid + 256 * it, ii = item & 31, kq = item >> 5;
+                Ws[(4 * kq + 0) * HEAD_T + ii] = sw[it].x;
+                Ws[(4 * kq + 1) * HEAD_T + ii] = sw[it].y;
+                Ws[(4 * kq + 2) * HEAD_T + ii] = sw[it].z;
+                Ws[(4 * kq + 3) * HEAD_T + ii] = sw[it].w;
+            }
+        }
+        __syncthreads();
+        if (blockIdx.y == 0) {             // Wt[k0 + k][I0 + ii]
+            for (int item = tid; item < kc * HEAD_T; item += 256) {
+                const int k = item >> 5, ii = item & 31;
+                if (I0 + ii < d) Wt[(size_t)(k0 + k) * d + I0 + ii] = Ws[k * HEAD_T + ii];
+            }
+        }
+        if (blockIdx.x == 0) {             // Ap[k0 + k][J0 + jj]
+            for (int item = tid; item < kc * HEAD_T; item += 256) {
+                const int k = item >> 5, jj = item & 31;
+                const int j = J0 + jj;
+                if (j < lda) {
+                    float v = As[k * HEAD_T + jj];                 // 0 for j >= r
+                    if (j == k0 + k) v = -1.0f / (v + 1.0f);
+                    Ap[(size_t)(k0 + k) * lda + j] = v;
+                }
+            }
+        }
+#pragma unroll 8
+        for (int k = 0; k < kc; ++k) {
+            const float2 a = *reinterpret_cast<const float2*>(As + k * HEAD_T + tj);
+            const float2 w = *reinterpret_cast<const float2*>(Ws + k * HEAD_T + ti);
+            acc[0][0] = fmaf(a.x, w.x, acc[0][0]);
+            acc[0][1] = fmaf(a.x, w.y, acc[0][1]);
+            acc[1][0] = fmaf(a.y, w.x, acc[1][0]);
+            acc[1][1] = fmaf(a.y, w.y, acc[1][1]);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int j = J0 + tj + a, i = I0 + ti + c;
+            if (j < r && i < d) Qt0[(size_t)j * d + i] = acc[a][c] - bsub[a][c];
+        }
 }
 
 template <int RPT>
@@ -422,23 +552,28 @@ int launch_dict_pass(onmf_ctx* c, int d, int r, const float* Win, const float* A
             c->dict_coop_last = true;
         }
         if (part != 2) {
-            // Qt0[j][i] = sum_k A[k][j] * W[i][k] - B[j][i]
-            ONMF_TRY(launch_gemm(c, /*a_km=*/true, /*b_kn=*/false, r, d, r, A, r, Win, r, 1.f, -1.f, B,
-                                 Qt, d, s, &c->slab_side, /*no_split=*/true));
-            ONMF_TRY(launch_transpose(d, r, Win, Wt, s));
-            hipLaunchKernelGGL(dict_pad_kernel, dim3(r), dim3(64), 0, s, r, lda, A, Ap);
+            // Qt0 = A^T W^T - B, Wt = W^T and the padded A, one launch
+            static LdsLimit lim;
+            constexpr size_t head_lds = 2 * (size_t)HEAD_KC * HEAD_T * sizeof(float);
+            ONMF_TRY(onmf_raise_lds_limit(c, lim, (const void*)dict_head_kernel, head_lds));
+            hipLaunchKernelGGL(dict_head_kernel, dim3((d + HEAD_T - 1) / HEAD_T, (lda + HEAD_T - 1) / HEAD_T),
+                               dim3(256), head_lds, s, d, r, lda, A, Win, B, Qt, Wt, Ap);
             HIP_TRY(c, hipGetLastError());
         }
         // 256 threads, thread t owns rows t, t + 256, ... of its workgroup's 1024
         const int rpt = nwg > 1 ? 4 : (d + 255) / 256;
         const int nt = rpt > 1 ? 256 : (d + 63) / 64 * 64;
         const long long spin_limit = 200000000LL;   // 2 s of the 100 MHz wall clock
+        // (The workgroup shares its CU with one workgroup of the product that runs beside it.  Claiming
+        // the CU whole - through a large LDS request - was measured: the pass gets no faster, and the
+        // product loses a second slot in that shader engine, which at 15 of 16 slots taken per engine
+        // leaves one of its workgroups waiting for the pass to end.)
 #define PANEL_CASE(RPTV)                                                                              \
     hipLaunchKernelGGL((dict_panel_kernel<RPTV>), dim3(nwg), dim3(nt), 0, s, d, r, lda, Qt, Ap, Wt, WtOut, Dt, \
-                       nwg, gran, flag, spin_limit, j_begin, j_end)
-        if (rpt <= 1) PANEL_CASE(1);
-        else if (rpt <= 2) PANEL_CASE(2);
-        else PANEL_CASE(4);
+                       nwg, gran, flag, spin_limit, j_begin, j_end);
+        if (rpt <= 1) PANEL_CASE(1)
+        else if (rpt <= 2) PANEL_CASE(2)
+        else PANEL_CASE(4)
 #undef PANEL_CASE
         HIP_TRY(c, hipGetLastError());
         if (part == 1) return ONMF_OK;

@@ -50,6 +50,8 @@ struct GemmParams {
     // (two products that share A in one launch); n1 == 0: none
     const float* B2;
     int ldb2, n1, vecB2;
+    int prio;     // raise the waves' priority: a small product at the head of a latency chain that runs
+                  // beside a chip-filling kernel of another stream
 };
 
 // Global -> registers for one BK x 128 operand tile (4 float4 per thread).
@@ -167,6 +169,7 @@ struct TileSource {
 template <bool A_KM, bool B_KN>
 __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    if (p.prio) __builtin_amdgcn_s_setprio(3);
     // layout: [A buf0][A buf1][B buf0][B buf1]
     constexpr int A_STRIDE = TILE_ELEMS;
     constexpr int B_STRIDE = TILE_ELEMS;
@@ -346,6 +349,7 @@ int launch_gemm(onmf_ctx* c, bool a_km, bool b_kn, int M, int N, int K, const fl
     p.vecA = (((uintptr_t)A & 15) == 0 && (lda & 3) == 0) ? 1 : 0;
     p.vecB = (((uintptr_t)B & 15) == 0 && (ldb & 3) == 0) ? 1 : 0;
     p.B2 = nullptr; p.ldb2 = 0; p.n1 = 0; p.vecB2 = 0;
+    p.prio = no_split ? 1 : 0;
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     p.tiles_n = tiles_n;
     const int tiles = tiles_m * tiles_n;
@@ -412,6 +416,7 @@ int launch_gemm_nt_pair(onmf_ctx* c, int M, int K, const float* A, int lda, cons
     p.vecA = (((uintptr_t)A & 15) == 0 && (lda & 3) == 0) ? 1 : 0;
     p.vecB = (((uintptr_t)B1 & 15) == 0 && (ldb1 & 3) == 0) ? 1 : 0;
     p.B2 = B2; p.ldb2 = ldb2; p.n1 = N1;
+    p.prio = 0;
     p.vecB2 = (((uintptr_t)B2 & 15) == 0 && (ldb2 & 3) == 0) ? 1 : 0;
     p.tiles_n = tiles_n;
     const int kt_per = (ktiles + splits - 1) / splits;

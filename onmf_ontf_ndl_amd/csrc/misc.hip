@@ -120,6 +120,7 @@ __global__ __launch_bounds__(256) void unfold3_kernel(int n0, int n1, int n2, co
 __global__ __launch_bounds__(256) void transpose_kernel(int rows, int cols, const float* __restrict__ in,
                                                         float* __restrict__ out) {
     __shared__ float tile[32][33];
+    __builtin_amdgcn_s_setprio(3);     // small and often in a latency chain beside a chip-filling kernel
     const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
     for (int k = ty; k < 32; k += 8) {
