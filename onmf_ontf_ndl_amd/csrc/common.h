@@ -108,9 +108,7 @@ inline int onmf_raise_lds_limit(onmf_ctx* c, LdsLimit& lim, const void* kernel, 
 // b_kn: B(k,n)=B[k*ldb+n] else B[n*ldb+k].  Cin may be null when beta == 0; Cin may alias C.
 int launch_gemm(onmf_ctx* c, bool a_km, bool b_kn, int M, int N, int K, const float* A, int lda,
                 const float* B, int ldb, float alpha, float beta, const float* Cin, float* C,
-                int ldc, hipStream_t s, DevBuf* slab = nullptr, bool no_split = false);
-// (no_split: one workgroup per output tile whatever the shape - for a product that starts a latency
-// chain beside a chip-filling kernel, where a second launch to add slabs costs more than it saves)
+                int ldc, hipStream_t s, DevBuf* slab = nullptr);
 
 // Two products that share the left operand, A B1^T and A B2^T (all operands contraction-fast), in one
 // launch where the shapes allow; see gemm.hip.

@@ -139,24 +139,13 @@ __device__ __forceinline__ float wave_sum_uniform(float x) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
 }
 
-// Ap[k][0..lda) = A[k][0..r) followed by zeros, except the diagonal, which the pass never reads as
-// an entry of A: Ap[k][k] = -1 / (A[k][k] + 1), the (negated) step of atom k
-__global__ void dict_pad_kernel(int r, int lda, const float* __restrict__ A, float* __restrict__ Ap) {
-    __builtin_amdgcn_s_setprio(3);
-    const int k = blockIdx.x;
-    for (int j = threadIdx.x; j < lda; j += blockDim.x) {
-        float v = j < r ? A[(size_t)k * r + j] : 0.f;
-        if (j == k) v = -1.0f / (v + 1.0f);
-        Ap[(size_t)k * lda + j] = v;
-    }
-}
-
 // Everything the panel kernel reads, in ONE launch of many small workgroups (one dependent round
 // trip to memory each), because this is the head of a latency chain that runs beside a chip-filling
 // product of another stream, where every dependent memory access costs several times its usual time:
 //   Qt0[j][i] = sum_k A[k][j] W[i][k] - B[j][i]      (r x d; src/onmf.py:112 before any atom has moved)
 //   Wt[k][i]  = W[i][k]                              (r x d)
-//   Ap        = A padded to lda columns, diagonal replaced by -1 / (A[k][k] + 1)
+//   Ap        = A padded to lda columns, except the diagonal, which the pass never reads as an entry
+//               of A: Ap[k][k] = -1 / (A[k][k] + 1), the (negated) step of atom k
 // A workgroup owns a tile of 32 atoms x 32 rows; per chunk of up to 256 k it stages A[k][J0..J0+31] and
 // W[I0..I0+31][k] (transposed) in LDS, 64 KB, and every thread accumulates 2 x 2 outputs.  The tiles
 // with J0 == 0 also write their rows of Wt, those with I0 == 0 their columns of Ap.

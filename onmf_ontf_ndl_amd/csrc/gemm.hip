@@ -50,8 +50,6 @@ struct GemmParams {
     // (two products that share A in one launch); n1 == 0: none
     const float* B2;
     int ldb2, n1, vecB2;
-    int prio;     // raise the waves' priority: a small product at the head of a latency chain that runs
-                  // beside a chip-filling kernel of another stream
 };
 
 // Global -> registers for one BK x 128 operand tile (4 float4 per thread).
@@ -169,7 +167,6 @@ struct TileSource {
 template <bool A_KM, bool B_KN>
 __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    if (p.prio) __builtin_amdgcn_s_setprio(3);
     // layout: [A buf0][A buf1][B buf0][B buf1]
     constexpr int A_STRIDE = TILE_ELEMS;
     constexpr int B_STRIDE = TILE_ELEMS;
@@ -338,7 +335,7 @@ int run(onmf_ctx* c, const GemmParams& p, dim3 grid, hipStream_t s) {
 
 int launch_gemm(onmf_ctx* c, bool a_km, bool b_kn, int M, int N, int K, const float* A, int lda,
                 const float* B, int ldb, float alpha, float beta, const float* Cin, float* C,
-                int ldc, hipStream_t s, DevBuf* slab, bool no_split) {
+                int ldc, hipStream_t s, DevBuf* slab) {
     if (!slab) slab = &c->slab;
     if (M <= 0 || N <= 0 || K < 0) return onmf_fail(c, ONMF_ERR_ARG, "gemm: bad shape %dx%dx%d", M, N, K);
     if (beta != 0.f && Cin == nullptr) return onmf_fail(c, ONMF_ERR_ARG, "gemm: beta without Cin");
@@ -349,13 +346,12 @@ int launch_gemm(onmf_ctx* c, bool a_km, bool b_kn, int M, int N, int K, const fl
     p.vecA = (((uintptr_t)A & 15) == 0 && (lda & 3) == 0) ? 1 : 0;
     p.vecB = (((uintptr_t)B & 15) == 0 && (ldb & 3) == 0) ? 1 : 0;
     p.B2 = nullptr; p.ldb2 = 0; p.n1 = 0; p.vecB2 = 0;
-    p.prio = no_split ? 1 : 0;
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     p.tiles_n = tiles_n;
     const int tiles = tiles_m * tiles_n;
     const int ktiles = (K + BK - 1) / BK;
     int splits = 1;
-    if (tiles < 256 && ktiles >= 4 && !no_split) {
+    if (tiles < 256 && ktiles >= 4) {
         // few tiles: one workgroup per CU is enough, and half as many slabs for the reduction to read;
         // otherwise a little under two per CU, so that the launch is still ONE round of workgroups when
         // a small kernel on another stream holds a few of the chip's slots (with exactly two per CU a
@@ -416,7 +412,6 @@ int launch_gemm_nt_pair(onmf_ctx* c, int M, int K, const float* A, int lda, cons
     p.vecA = (((uintptr_t)A & 15) == 0 && (lda & 3) == 0) ? 1 : 0;
     p.vecB = (((uintptr_t)B1 & 15) == 0 && (ldb1 & 3) == 0) ? 1 : 0;
     p.B2 = B2; p.ldb2 = ldb2; p.n1 = N1;
-    p.prio = 0;
     p.vecB2 = (((uintptr_t)B2 & 15) == 0 && (ldb2 & 3) == 0) ? 1 : 0;
     p.tiles_n = tiles_n;
     const int kt_per = (ktiles + splits - 1) / splits;

@@ -2,7 +2,7 @@
 --kernel-trace database of bench.py, e.g.
 
     rocprofv3 --kernel-trace -d out -o bench -- python3 bench.py --no-cpu-baseline --no-also
-    python3 tools/step_timeline.py out/bench_results.db
+    python3 tools/step_timeline.py out/bench_results.db [steps back from the end] [sweep kernel name part]
 """
 import sqlite3
 import sys
@@ -11,8 +11,9 @@ import sys
 def main():
     db = sqlite3.connect(sys.argv[1])
     back = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    which = sys.argv[3] if len(sys.argv) > 3 else "sweep_tile_kernel<16,"     # the headline shape's sweep kernel
     rows = list(db.execute("select name,start,end,grid_x,grid_y,grid_z,workgroup_x,queue_id from kernels order by start"))
-    sweeps = [i for i, r in enumerate(rows) if "sweep_tile_kernel" in r[0]]
+    sweeps = [i for i, r in enumerate(rows) if which in r[0]]
     lo, hi = sweeps[-back - 1] + 1, sweeps[-back] + 1
     t0 = rows[lo][1]
     for r in rows[lo:hi + 3]:
