@@ -428,6 +428,32 @@ def test_step_with_a_tall_dictionary_against_oracle(eng, orc):
     assert relerr(host(W1), W_o) < TOL_W
 
 
+@pytest.mark.parametrize("d,r,b", [(64, 130, 33001), (32, 256, 32768), (48, 100, 70000)])
+def test_last_columns_of_the_big_product_come_from_the_side_stream(eng, d, r, b):
+    """When W^T X is a whole number of chip rounds, its last columns are computed by a separate launch
+    on a second stream (contraction split, other summation order).  One sweep from the same start
+    must give the same code as the single-launch path (second stream off) to rounding - an indexing
+    slip in the column ranges would show as O(1) differences in the last columns."""
+    import torch
+    g = torch.Generator(device=eng.device).manual_seed(b + r)
+    X = torch.rand(d, b, device=eng.device, generator=g)
+    W = torch.rand(d, r, device=eng.device, generator=g)
+    W = W / torch.clamp(torch.linalg.norm(W, dim=0), min=1.0)
+    H0 = torch.rand(r, b, device=eng.device, generator=g)
+    Hs, _, _ = eng.sparse_code(X, W, H0=H0, sub_iter=1, stopping_diff=0.0)
+    eng.set_option(4, 0)                 # no second stream: one launch for all columns
+    try:
+        H1, _, _ = eng.sparse_code(X, W, H0=H0, sub_iter=1, stopping_diff=0.0)
+    finally:
+        eng.set_option(4, 1)
+    assert float((Hs - H1).abs().max()) <= 1e-5 * max(1.0, float(H1.abs().max()))
+    # and against float64 on the last 5000 columns
+    Xh, Wh, H0h = host(X[:, -5000:]), host(W), host(H0[:, -5000:])
+    from oracle import onmf_oracle as orc
+    Href = orc.code_sweeps(Xh, Wh, H0=H0h, sub_iter=1, stopping_diff=0.0)
+    assert relerr(host(Hs[:, -5000:]), Href) <= TOL_H
+
+
 def test_full_size_step_equals_its_parts(eng):
     """d = 1024, r = 256, b = 65536 (the headline shape): one step call - all sweeps in one launch,
     dictionary pass in two parts beside the products - gives bit for bit what the three entry points give
