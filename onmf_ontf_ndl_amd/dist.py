@@ -7,9 +7,9 @@ H H^T and H X^T (src/onmf.py:155-156) and the replicated dictionary.  Two ways t
   with its own (W, A, B) and, every few steps, the ranks all-reduce the packed state [A | B | W] and
   divide by the world size.  Averages of nonnegative matrices with column norms <= 1 stay in that
   set, so W needs no re-projection.  One collective of r*r + 2*r*d floats per exchange.
-* one large minibatch split by columns (``allreduce_partial_aggregates``): each rank codes its slice
-  and the partial sums are added before the (1-w, w) recursion - equal to the reference run on the
-  concatenated batch up to summation order.
+* one large minibatch split by columns (``sharded_step``, built on ``allreduce_partial_aggregates``):
+  each rank codes its slice and the partial sums are added before the (1-w, w) recursion - equal to
+  the reference run on the concatenated batch up to summation order.
 
 Both helpers work on any tensor device; under the ``gloo`` backend device tensors are staged through
 host memory.
@@ -99,6 +99,32 @@ def allreduce_partial_aggregates(HHt, HXt, group=None):
     HHt.copy_(flat[:n].reshape(HHt.shape))
     HXt.copy_(flat[n:].reshape(HXt.shape))
     return HHt, HXt
+
+
+def sharded_step(eng, X_local, A, B, W, w, *, alpha=0.0, H0=None, seed=None, sub_iter=10,
+                 stopping_diff=0.0, group=None):
+    """One minibatch step (src/onmf.py:119-167) on a minibatch whose columns are split over the ranks.
+
+    Every rank holds the same (W, A, B) and its own columns ``X_local``.  It codes them, forms its
+    partial sums H H^T and H X^T (src/onmf.py:155-156 are sums over columns), the ranks add them
+    with one collective, and every rank applies the (1 - w, w) recursion and the dictionary pass -
+    on the OLD aggregates, as the reference does (src/onmf.py:161) - to identical inputs, so the
+    state stays replicated without a broadcast.  The result equals the reference's step on the
+    concatenated batch up to summation order when ``stopping_diff <= 0`` (fixed sweep count); with a
+    positive tolerance each rank applies the stopping test to its own columns, which the reference
+    applies to the whole batch.
+
+    ``eng`` is an ``Engine`` (or anything with its ``sparse_code`` / ``aggregate`` / ``update_dict``).
+    Returns (H_local, A1, B1, W1, sweeps).
+    """
+    H, sweeps, _ = eng.sparse_code(X_local, W, H0=H0, alpha=alpha, sub_iter=sub_iter,
+                                   stopping_diff=stopping_diff, seed=seed)
+    HHt, HXt, _ = eng.aggregate(X_local, H, 1.0, None, None)        # w = 1, no old part: the bare sums
+    allreduce_partial_aggregates(HHt, HXt, group)
+    A1 = (1.0 - w) * A + w * HHt
+    B1 = (1.0 - w) * B + w * HXt
+    W1 = eng.update_dict(W, A, B)
+    return H, A1, B1, W1, sweeps
 
 
 def split_columns(n, rank, world):

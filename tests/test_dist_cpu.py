@@ -43,6 +43,33 @@ def _worker(rank, world, init_file, out_dir):
         H_all = orc.code_sweeps(X, Wd, H0=H0, alpha=0, sub_iter=10, stopping_diff=-1.0)
         np.testing.assert_allclose(HHt.numpy(), H_all @ H_all.T, rtol=1e-10)
         np.testing.assert_allclose(HXt.numpy(), H_all @ X.T, rtol=1e-10)
+        # the whole sharded step, with the oracle standing in for the GPU engine: equals the reference's
+        # step on the concatenated batch (fixed sweep count), and the state stays replicated
+        class OracleEngine:
+            def sparse_code(self, X, W, H0=None, alpha=0.0, sub_iter=10, stopping_diff=0.0, seed=None):
+                H = orc.code_sweeps(X.numpy(), W.numpy(), H0=H0.numpy(), alpha=alpha, sub_iter=sub_iter,
+                                    stopping_diff=-1.0)
+                return torch.from_numpy(H), sub_iter, None
+
+            def aggregate(self, X, H, w, A, B):
+                assert w == 1.0 and A is None and B is None
+                return H @ H.T, H @ X.T, None
+
+            def update_dict(self, W, A, B):
+                return torch.from_numpy(orc.dictionary_pass(W.numpy(), A.numpy(), B.numpy()))
+
+        A0 = torch.from_numpy(full.rand(r, r)); A0 = A0 @ A0.T
+        B0 = torch.from_numpy(full.rand(r, d))
+        Wt = torch.from_numpy(Wd)
+        t = 3
+        H_l, A1, B1, W1, sw = odist.sharded_step(OracleEngine(), torch.from_numpy(X[:, lo:hi]), A0, B0, Wt, 1.0 / t,
+                                                 H0=torch.from_numpy(H0[:, lo:hi]), sub_iter=10, stopping_diff=0.0)
+        Href, (Aref, Bref), Wref, _ = orc.minibatch_step(X, [A0.numpy(), B0.numpy()], Wd, t, H0=H0, sub_iter=10,
+                                                         stopping_diff=-1.0)
+        np.testing.assert_allclose(H_l.numpy(), Href[:, lo:hi], rtol=1e-10, atol=1e-14)
+        np.testing.assert_allclose(A1.numpy(), Aref, rtol=1e-10)
+        np.testing.assert_allclose(B1.numpy(), Bref, rtol=1e-10)
+        np.testing.assert_allclose(W1.numpy(), Wref, rtol=1e-10, atol=1e-14)
         open(os.path.join(out_dir, "ok%d" % rank), "w").write("ok")
     finally:
         td.destroy_process_group()

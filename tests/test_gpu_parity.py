@@ -454,6 +454,27 @@ def test_last_columns_of_the_big_product_come_from_the_side_stream(eng, d, r, b)
     assert relerr(host(Hs[:, -5000:]), Href) <= TOL_H
 
 
+def test_sharded_step_without_a_process_group_is_the_plain_step(eng):
+    """dist.sharded_step (code, partial sums, collective, recursion, dictionary pass) with no process
+    group must reproduce eng.step at a fixed sweep count - only the recursion's arithmetic differs
+    (separate multiply-adds instead of the product's epilogue)."""
+    import torch
+    from onmf_ontf_ndl_amd import dist as odist
+    g = torch.Generator(device=eng.device).manual_seed(77)
+    d, r, b = 96, 24, 1500
+    X = torch.rand(d, b, device=eng.device, generator=g)
+    W = eng.update_dict(torch.rand(d, r, device=eng.device, generator=g), eng.zeros(r, r), eng.zeros(r, d))
+    H0 = torch.rand(r, b, device=eng.device, generator=g)
+    Hh = torch.rand(r, 300, device=eng.device, generator=g)
+    A = Hh @ Hh.T
+    B = Hh @ torch.rand(d, 300, device=eng.device, generator=g).T
+    H1, A1, B1, _, W1, s1, _ = eng.step(X, A, B, None, W, 0.25, H0=H0, sub_iter=10, stopping_diff=0.0)
+    H2, A2, B2, W2, s2 = odist.sharded_step(eng, X, A, B, W, 0.25, H0=H0, sub_iter=10, stopping_diff=0.0)
+    assert s1 == s2 == 10
+    assert torch.equal(H1, H2) and torch.equal(W1, W2)
+    assert relerr(host(A2), host(A1)) <= 1e-6 and relerr(host(B2), host(B1)) <= 1e-6
+
+
 def test_full_size_step_equals_its_parts(eng):
     """d = 1024, r = 256, b = 65536 (the headline shape): one step call - all sweeps in one launch,
     dictionary pass in two parts beside the products - gives bit for bit what the three entry points give
