@@ -226,7 +226,9 @@ double onmf_host_lambda_max(const float* S_host, int n);
  *   ONMF_OPT_SWEEP_KERNEL  0 = pick by shape, 1 = column-per-lane kernel, 2 = MFMA tile kernel
  *                          (3 / 4: tile kernel pinned to 1 / 2 column tiles of 16 per wave).
  *   ONMF_OPT_OVERLAP_DICT  != 0 (default): onmf_step runs the dictionary pass on a second stream
- *                          beside the code solve when no output aliases an input.
+ *                          beside the two big products when no output aliases an input, and the
+ *                          code solve's small set-up work (and the last columns of W^T X) on a
+ *                          third; 0: everything in order on the caller's stream.
  *   ONMF_OPT_SCREEN_STOP   != 0 (default): decide the stopping test on the device from rigorous
  *                          bounds that the sweep kernel produces as by-products, all sweeps
  *                          enqueued without host round trips; the full test runs only where the
