@@ -312,7 +312,7 @@ def test_step_against_oracle(eng, orc, d, r, b, kernel):
 
 @pytest.mark.parametrize("kernel", [1, 2])
 @pytest.mark.parametrize("shape", [(1500, 48), (64, 16), (1024, 256), (2500, 40), (700, 23), (300, 100), (33, 7),
-                                   (4096, 64), (5000, 17)])
+                                   (4096, 64), (5000, 17), (200, 300), (130, 513)])
 def test_update_dict_both_kernels(eng, orc, kernel, shape):
     """The dictionary pass with cooperating one-wave workgroups (1; d = 1500 -> 24 of them) and with the
     panel kernel (2; one workgroup per 1024 rows, which exchange the atoms' norms when there are
