@@ -285,7 +285,7 @@ def test_g8_stream_of_warm_restarts(eng):
 # against the oracle on seeded inputs (sizes the oracle finishes in seconds)
 # ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("d,r,b", [(100, 16, 1000), (441, 25, 1000), (300, 100, 517), (256, 64, 2048),
-                                   (64, 256, 300), (33, 7, 1)])
+                                   (64, 256, 300), (33, 7, 1), (90, 300, 700)])
 @pytest.mark.parametrize("kernel", [1, 0])
 def test_step_against_oracle(eng, orc, d, r, b, kernel):
     rs = np.random.RandomState(d + r + b)
