@@ -100,6 +100,41 @@ __global__ __launch_bounds__(1024 / CT) void sweep_tile_kernel(
         if (reinterpret_cast<const int*>(sc.base)[ScreenLayout::FLAG] != 0) return;
     }
 
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int c_lane = lane & 15;          // column of the tile (doubles as the A-operand row index)
+    const int g_lane = lane >> 4;          // lane group: rows 4g .. 4g+3 of every block
+
+    // H and Cm go through buffer descriptors: byte address = (per-lane voffset) + (wave-uniform
+    // soffset = row offset * b), no per-access address registers, and the hardware range check
+    // returns 0 for rows >= r (their offset is past r*b floats) and drops such stores.  Columns
+    // >= b get an out-of-range offset: they load zeros, run the arithmetic on zeros (alpha is
+    // masked for them too, so they stay zero) and their stores are dropped.
+    // The host guarantees r * b * 4 < 2^31.
+    const unsigned nbytes = (unsigned)r * (unsigned)b * 4u;
+    const auto rs_c = __builtin_amdgcn_make_buffer_rsrc((void*)Cm, 0, nbytes, 0x00020000);
+    int voff[CT];
+    float alpha_c[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int col = ((blockIdx.x * WAVES + wave) * CT + ct) * 16 + c_lane;
+        voff[ct] = col < b ? (4 * g_lane * b + col) * 4 : (int)0x80000000;
+        alpha_c[ct] = col < b ? alpha : 0.f;
+    }
+    float h[CT][NB][4];
+    {
+        float* hin = (k_first % 3 == 0) ? hb0 : (k_first % 3 == 1) ? hb1 : hb2;
+        const auto rs_h = __builtin_amdgcn_make_buffer_rsrc((void*)hin, 0, nbytes, 0x00020000);
+#pragma unroll
+        for (int J = 0; J < NB; ++J)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    h[ct][J][t] = __uint_as_float(
+                        __builtin_amdgcn_raw_buffer_load_b32(rs_h, voff[ct], (16 * J + t) * b * 4, 0));
+    }
+    // (H is requested first: its loads are in flight while Gm is staged)
     // ---- stage Gm into LDS (whole workgroup): one float4 (4 consecutive columns of one row of a
     // block) per item, all of a thread's loads in flight together ----
     {
@@ -151,40 +186,6 @@ __global__ __launch_bounds__(1024 / CT) void sweep_tile_kernel(
         for (int e = tid; e < NB * 256; e += NT) Us[e] = sc.base[ScreenLayout::UBLK + e];
     }
 
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int c_lane = lane & 15;          // column of the tile (doubles as the A-operand row index)
-    const int g_lane = lane >> 4;          // lane group: rows 4g .. 4g+3 of every block
-
-    // H and Cm go through buffer descriptors: byte address = (per-lane voffset) + (wave-uniform
-    // soffset = row offset * b), no per-access address registers, and the hardware range check
-    // returns 0 for rows >= r (their offset is past r*b floats) and drops such stores.  Columns
-    // >= b get an out-of-range offset: they load zeros, run the arithmetic on zeros (alpha is
-    // masked for them too, so they stay zero) and their stores are dropped.
-    // The host guarantees r * b * 4 < 2^31.
-    const unsigned nbytes = (unsigned)r * (unsigned)b * 4u;
-    const auto rs_c = __builtin_amdgcn_make_buffer_rsrc((void*)Cm, 0, nbytes, 0x00020000);
-    int voff[CT];
-    float alpha_c[CT];
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-        const int col = ((blockIdx.x * WAVES + wave) * CT + ct) * 16 + c_lane;
-        voff[ct] = col < b ? (4 * g_lane * b + col) * 4 : (int)0x80000000;
-        alpha_c[ct] = col < b ? alpha : 0.f;
-    }
-    float h[CT][NB][4];
-    {
-        float* hin = (k_first % 3 == 0) ? hb0 : (k_first % 3 == 1) ? hb1 : hb2;
-        const auto rs_h = __builtin_amdgcn_make_buffer_rsrc((void*)hin, 0, nbytes, 0x00020000);
-#pragma unroll
-        for (int J = 0; J < NB; ++J)
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    h[ct][J][t] = __uint_as_float(
-                        __builtin_amdgcn_raw_buffer_load_b32(rs_h, voff[ct], (16 * J + t) * b * 4, 0));
-    }
     float ub = PROBE ? sc.base[ScreenLayout::UBH + sc.v_first] : -1.0f;    // bound carried by wave 0
     bool active = true;                    // EACH: this lane's column is still iterating
     int col_sweeps = 0;
