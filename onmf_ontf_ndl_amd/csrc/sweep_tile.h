@@ -186,6 +186,12 @@ __global__ __launch_bounds__(1024 / CT) void sweep_tile_kernel(
         for (int e = tid; e < NB * 256; e += NT) Us[e] = sc.base[ScreenLayout::UBLK + e];
     }
 
+    float cmn[CT][4];                      // Cm of the block that comes next (block 0 to begin with)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            cmn[ct][t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_c, voff[ct], t * b * 4, 0));
     float ub = PROBE ? sc.base[ScreenLayout::UBH + sc.v_first] : -1.0f;    // bound carried by wave 0
     bool active = true;                    // EACH: this lane's column is still iterating
     int col_sweeps = 0;
@@ -263,14 +269,9 @@ __global__ __launch_bounds__(1024 / CT) void sweep_tile_kernel(
         f32x4 pacc[CT];
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) pacc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // Cm is touched once per sweep and fetched one block ahead: alpha - Cm is what the block's
-        // accumulator starts from, so the MFMAs leave the gradient itself
-        float cmn[CT][4];
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-                cmn[ct][t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_c, voff[ct], t * b * 4, 0));
+        // (Cm is touched once per sweep and fetched one block ahead - cmn, requested before the loop and
+        // at the end of the sweep before: alpha - Cm is what the block's accumulator starts from, so
+        // the MFMAs leave the gradient itself)
 
     #pragma unroll
         for (int K = 0; K < NB; ++K) {
@@ -287,13 +288,15 @@ __global__ __launch_bounds__(1024 / CT) void sweep_tile_kernel(
                 for (int t = 0; t < 4; ++t) acc0[ct][t] = alpha_c[ct] - cmn[ct][t];
                 acc1[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            if (K + 1 < NB) {
+            {
+                // the last block fetches block 0 again: the next sweep starts without waiting for it
+                const int Kn = (K + 1 < NB) ? K + 1 : 0;
     #pragma unroll
                 for (int ct = 0; ct < CT; ++ct)
     #pragma unroll
                     for (int t = 0; t < 4; ++t)
                         cmn[ct][t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
-                            rs_c, voff[ct], (16 * (K + 1) + t) * bk * 4, 0));
+                            rs_c, voff[ct], (16 * Kn + t) * bk * 4, 0));
             }
     #pragma unroll
             for (int J = 0; J < NB; ++J) {
