@@ -229,8 +229,10 @@ __device__ __forceinline__ int screen_verdict(float lb2, double dsum, double hsu
 // whose stores a plain load could miss in this XCD's L2.  `ub` carries the bound of
 // sigma_max(H before sweep j) in and the bound for sweep j + 1 out.  With `record` the caller is the
 // one workgroup that writes the verdict down.  Returns the verdict, wave-uniform.
+// `seeded` >= 0: the caller has already read base[UBH + j + 1] (it may do so while it still waits for
+// the sweep's count: one memory round trip less on the way to the verdict); < 0: read it here.
 __device__ __forceinline__ int screen_eval_wave(float* base, int j, float& ub, float tol, float rank_cap,
-                                                bool record) {
+                                                bool record, float seeded_in = -1.0f) {
     const int lane = threadIdx.x & 63;
     float* set = base + ScreenLayout::SETS + j * ScreenLayout::SETSZ;
     // all loads of the wave go out together (one memory round trip): lanes 0-15 the probe energies,
@@ -261,7 +263,7 @@ __device__ __forceinline__ int screen_eval_wave(float* base, int j, float& ub, f
         // a bound for the next sweep that was put there before the launch (Collatz-Wielandt, or the
         // host's exact value) stands if it is the tighter one; every workgroup reads the same value
         // or the minimum already taken with it, so all arrive at the same number
-        const float seeded = base[ScreenLayout::UBH + j + 1];
+        const float seeded = seeded_in >= 0.f ? seeded_in : base[ScreenLayout::UBH + j + 1];
         if (seeded > 0.f && seeded < ubn) ubn = seeded;
         if (record) {
             float* rec = base + ScreenLayout::REC + 4 * j;

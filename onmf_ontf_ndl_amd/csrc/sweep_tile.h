@@ -204,6 +204,8 @@ __global__ __launch_bounds__(1024 / CT) void sweep_tile_kernel(
                 const int j = k - 2;
                 if (j >= sc.v_first) {
                     const int* cnt = reinterpret_cast<const int*>(sc.base) + ScreenLayout::CNT + j;
+                    // (requested together with the first look at the count; 0 = none, as negative)
+                    const float seeded = fmaxf(sc.base[ScreenLayout::UBH + j + 1], 0.f);
                     const long long t0 = wall_clock64();
                     for (;;) {
                         // (the sums are read only after the count has been seen complete: they were
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(1024 / CT) void sweep_tile_kernel(
                         __builtin_amdgcn_s_sleep(4);
                     }
                     if (verdict == 0) {
-                        verdict = screen_eval_wave(sc.base, j, ub, sc.tol, sc.rank_cap, blockIdx.x == 0);
+                        verdict = screen_eval_wave(sc.base, j, ub, sc.tol, sc.rank_cap, blockIdx.x == 0, seeded);
                     } else if (lane == 0) {
                         __hip_atomic_store(reinterpret_cast<int*>(sc.base) + ScreenLayout::FLAG, verdict,
                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
