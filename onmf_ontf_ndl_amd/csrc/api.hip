@@ -388,10 +388,10 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
         if (ps != s && tiles_m * tiles_n >= 512 && cols <= b / 4) tail_cols = cols;
     }
     int prep_rc = ONMF_OK;
-    if (tail_cols)
-        prep_rc = launch_gemm(c, true, true, r, tail_cols, d, W, r, X + (b - tail_cols), ldx, 1.f, 0.f, nullptr,
-                              Cm + (b - tail_cols), b, ps, &c->slab_prep);
-    if (prep_rc == ONMF_OK)
+    if (tail_cols)   // [W^T X_tail | W^T W]: one launch and one reduction for both
+        prep_rc = launch_gemm_pair(c, true, true, r, d, W, r, X + (b - tail_cols), ldx, tail_cols, W, r, r, 1.f, 0.f,
+                                   nullptr, Cm + (b - tail_cols), b, 0.f, nullptr, Gm, r, ps, &c->slab_prep);
+    else
         prep_rc = launch_gemm(c, true, true, r, r, d, W, r, W, r, 1.f, 0.f, nullptr, Gm, r, ps,
                               ps == s ? nullptr : &c->slab_prep);
     if (prep_rc == ONMF_OK) {

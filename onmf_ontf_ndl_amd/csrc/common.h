@@ -112,6 +112,11 @@ int launch_gemm(onmf_ctx* c, bool a_km, bool b_kn, int M, int N, int K, const fl
 
 // Two products that share the left operand, A B1^T and A B2^T (all operands contraction-fast), in one
 // launch where the shapes allow; see gemm.hip.
+// (launch_gemm_pair: any operand layout - both B operands in the same one - and the slab set to use)
+int launch_gemm_pair(onmf_ctx* c, bool a_km, bool b_kn, int M, int K, const float* A, int lda, const float* B1,
+                     int ldb1, int N1, const float* B2, int ldb2, int N2, float alpha, float beta1, const float* Cin1,
+                     float* C1, int ldc1, float beta2, const float* Cin2, float* C2, int ldc2, hipStream_t s,
+                     DevBuf* slab);
 int launch_gemm_nt_pair(onmf_ctx* c, int M, int K, const float* A, int lda, const float* B1, int ldb1, int N1,
                         const float* B2, int ldb2, int N2, float alpha, float beta1, const float* Cin1, float* C1,
                         int ldc1, float beta2, const float* Cin2, float* C2, int ldc2, hipStream_t s);

@@ -396,14 +396,23 @@ int launch_gemm(onmf_ctx* c, bool a_km, bool b_kn, int M, int N, int K, const fl
 int launch_gemm_nt_pair(onmf_ctx* c, int M, int K, const float* A, int lda, const float* B1, int ldb1, int N1,
                         const float* B2, int ldb2, int N2, float alpha, float beta1, const float* Cin1, float* C1,
                         int ldc1, float beta2, const float* Cin2, float* C2, int ldc2, hipStream_t s) {
+    return launch_gemm_pair(c, false, false, M, K, A, lda, B1, ldb1, N1, B2, ldb2, N2, alpha, beta1, Cin1, C1, ldc1,
+                            beta2, Cin2, C2, ldc2, s, nullptr);
+}
+
+int launch_gemm_pair(onmf_ctx* c, bool a_km, bool b_kn, int M, int K, const float* A, int lda, const float* B1,
+                     int ldb1, int N1, const float* B2, int ldb2, int N2, float alpha, float beta1, const float* Cin1,
+                     float* C1, int ldc1, float beta2, const float* Cin2, float* C2, int ldc2, hipStream_t s,
+                     DevBuf* slab) {
+    if (!slab) slab = &c->slab;
     const int N = N1 + N2;
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     const int tiles = tiles_m * tiles_n;
     const int ktiles = (K + BK - 1) / BK;
     int splits = (tiles > 4 && tiles < 256 && ktiles >= 4) ? std::min(480 / tiles, ktiles / 2) : 1;
     if ((N1 % BN) != 0 || splits < 2 || (beta1 != 0.f && !Cin1) || (beta2 != 0.f && !Cin2)) {
-        ONMF_TRY(launch_gemm(c, false, false, M, N1, K, A, lda, B1, ldb1, alpha, beta1, Cin1, C1, ldc1, s));
-        return launch_gemm(c, false, false, M, N2, K, A, lda, B2, ldb2, alpha, beta2, Cin2, C2, ldc2, s);
+        ONMF_TRY(launch_gemm(c, a_km, b_kn, M, N1, K, A, lda, B1, ldb1, alpha, beta1, Cin1, C1, ldc1, s, slab));
+        return launch_gemm(c, a_km, b_kn, M, N2, K, A, lda, B2, ldb2, alpha, beta2, Cin2, C2, ldc2, s, slab);
     }
     GemmParams p;
     p.A = A; p.B = B1; p.Cin = Cin1; p.C = C1;
@@ -418,9 +427,17 @@ int launch_gemm_nt_pair(onmf_ctx* c, int M, int K, const float* A, int lda, cons
     splits = (ktiles + kt_per - 1) / kt_per;
     p.k_per_split = kt_per * BK;
     p.splits = splits;
-    ONMF_TRY(onmf_reserve(c, c->slab, (size_t)splits * M * N * sizeof(float), "split-K slabs"));
-    p.slab = (float*)c->slab.p;
-    ONMF_TRY((run<false, false>(c, p, dim3(tiles, 1, splits), s)));
+    ONMF_TRY(onmf_reserve(c, *slab, (size_t)splits * M * N * sizeof(float), "split-K slabs"));
+    p.slab = (float*)slab->p;
+    {
+        const dim3 grid(tiles, 1, splits);
+        int rc;
+        if (a_km && b_kn) rc = run<true, true>(c, p, grid, s);
+        else if (a_km && !b_kn) rc = run<true, false>(c, p, grid, s);
+        else if (!a_km && b_kn) rc = run<false, true>(c, p, grid, s);
+        else rc = run<false, false>(c, p, grid, s);
+        ONMF_TRY(rc);
+    }
     const size_t mn = (size_t)M * N;
     int blocks = (int)((mn + 63) / 64);
     if (blocks > 4096) blocks = 4096;
