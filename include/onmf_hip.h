@@ -30,9 +30,9 @@ extern "C" {
 #define ONMF_ERR_ARG (-1)       /* bad shape / null pointer / unsupported size          */
 #define ONMF_ERR_HIP (-2)       /* a HIP runtime call failed                             */
 #define ONMF_ERR_NOMEM (-3)     /* scratch allocation failed                             */
-#define ONMF_ERR_TIMEOUT (-4)   /* a bounded device-side wait gave up (dictionary pass)  */
+#define ONMF_ERR_TIMEOUT (-4)   /* a bounded device-side wait gave up and no retry was possible */
 
-#define ONMF_ABI_VERSION 1
+#define ONMF_ABI_VERSION 2
 
 /* coder_mode of onmf_sparse_code */
 #define ONMF_CODER_DAMPED 0 /* reference step 1/(sqrt(i+10)(G_kk+1)), src/onmf.py:257       */
@@ -61,6 +61,11 @@ const char* onmf_last_error(onmf_ctx* ctx);
  *               deciding bound (a lower bound of dist if the loop went on, an upper bound if it
  *               stopped); NaN for sweeps that did not run.
  *   The radius argument r of the reference is not supported: every caller passes r=None.
+ *   coder_mode ONMF_CODER_EXACT_CD: the loop ends when ||H - H_prev||_F / ||H_prev||_F <= stopping_diff
+ *               (Frobenius norms over the whole batch), tested on the last sweep of each chunk of
+ *               8, 16, 32, 64, 64, ... sweeps (one launch and one host round trip per chunk), or after
+ *               sub_iter sweeps; dist_trace holds the tested values and NaN for the sweeps in between.
+ *               onmf_sparse_code_each is the form with one test per column and no host round trip.
  */
 int onmf_sparse_code(onmf_ctx* ctx, int d, int r, int b, const float* X, int ldx, const float* W,
                      const float* H0, uint64_t seed, float alpha, int sub_iter,
@@ -77,9 +82,30 @@ int onmf_aggregate(onmf_ctx* ctx, int d, int r, int b, const float* X, int ldx, 
                    double w, const float* A_in, const float* B_in, const float* C_in, float* A_out,
                    float* B_out, float* C_out, void* stream);
 
-/* Online_NMF.update_dict(W, A, B), src/onmf.py:92-116 (same body: src/ontf.py:91-115). */
+/*
+ * Online_NMF.update_dict(W, A, B), src/onmf.py:92-116 (same body: src/ontf.py:91-115).
+ * For d > 1024 the pass runs on several workgroups that wait for each other's part of every atom's
+ * norm (bounded waits).  If one gives up - the workgroups were not resident together - the pass is
+ * redone atom by atom without such waits (slower, same result to rounding) and the event is counted
+ * (ONMF_CNT_DICT_TIMEOUTS); the call synchronises `stream` for d > 1024.
+ */
 int onmf_update_dict(onmf_ctx* ctx, int d, int r, const float* W_in, const float* A, const float* B,
                      float* W_out, void* stream);
+
+/*
+ * onmf_update_dict for callers that cannot allocate device memory (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments,
+ * same kernels and bit-identical results as onmf_update_dict, but the pass's workspace (the running
+ * product Q, the padded A, the atom deltas, W^T in and out) lives in a static device array of the
+ * library - 4.25 MB per GPU the library runs on, held until the process ends - instead of buffers the
+ * context allocates on demand.  Limits: d <= 1024 and r <= 256 (larger shapes return ONMF_ERR_ARG:
+ * use onmf_update_dict).  Calls neither hipMalloc nor hipFree nor any other allocating routine; asynchronous on `stream`,
+ * returns no host scalars.  Every call on a GPU uses that GPU's one array: calls that overlap on one
+ * GPU (two streams, two contexts, two threads) race.  Nothing carries over between calls - each call
+ * rewrites every part of the array that it reads.
+ */
+int onmf_update_dict_static(onmf_ctx* ctx, int d, int r, const float* W_in, const float* A, const float* B,
+                            float* W_out, void* stream);
 
 /*
  * Online_NMF.step(X, aggregates, W, t), src/onmf.py:119-167: code, aggregates, then the
@@ -91,6 +117,32 @@ int onmf_step(onmf_ctx* ctx, int d, int r, int b, const float* X, int ldx, const
               uint64_t seed, double w, float alpha, int sub_iter, float stopping_diff,
               float* H_out, float* A_out, float* B_out, float* C_out, float* W_out,
               int* sweeps_done, float* dist_trace, void* stream);
+
+/*
+ * The step for a minibatch whose columns are split over several GPUs (one process each).  The reference
+ * is single-process; what couples the columns of a minibatch is only the sums H H^T and H X^T of
+ * src/onmf.py:155-156.  Every rank holds the same (W, A, B) and its own columns X:
+ *   onmf_step_partial  codes the local columns (src/onmf.py:144), leaves the BARE local sums
+ *                      P_out = [ H H^T (r x r) | pad to a multiple of 4 floats | H X^T (r x d) ]
+ *                      (onmf_partial_floats(d, r) floats) and runs the dictionary pass on the aggregates
+ *                      from before the step (A_in, B_in; src/onmf.py:161) - in the same three-stream
+ *                      schedule as onmf_step.
+ *   (the host adds P over the ranks: one all-reduce)
+ *   onmf_step_apply    A_out = (1-w) A_in + w P[H H^T],  B_out = (1-w) B_in + w P[H X^T]
+ *                      (src/onmf.py:155-156 with the summed products); outputs may alias inputs.
+ * state_ready_event (hipEvent_t as void*, nullable): the dictionary pass and the aggregate products -
+ * the only parts that touch A_in, B_in and P_out - wait for it; the code solve does not.  A host that
+ * all-reduces the previous step's P and applies it on a stream of its own records the event there and so
+ * hides that exchange under this step's W^T X and sweeps (legal because the dictionary pass of step t
+ * needs the aggregates of step t-1 only).  With stopping_diff > 0 every rank tests its own columns.
+ */
+size_t onmf_partial_floats(int d, int r);
+int onmf_step_partial(onmf_ctx* ctx, int d, int r, int b, const float* X, int ldx, const float* W_in,
+                      const float* A_in, const float* B_in, const float* H0, uint64_t seed, float alpha,
+                      int sub_iter, float stopping_diff, float* H_out, float* P_out, float* W_out,
+                      int* sweeps_done, float* dist_trace, void* state_ready_event, void* stream);
+int onmf_step_apply(onmf_ctx* ctx, int d, int r, const float* P, double w, const float* A_in,
+                    const float* B_in, float* A_out, float* B_out, void* stream);
 
 /* X_batch = X[:, idx]  (src/onmf.py:214, src/ontf.py:231); idx: device int64[b]. */
 int onmf_gather_columns(onmf_ctx* ctx, int d, int n, const float* X, int ldx, const int64_t* idx,
@@ -238,10 +290,15 @@ double onmf_host_lambda_max(const float* S_host, int n);
  *   ONMF_OPT_PERSISTENT_SWEEPS != 0 (default): with the screened stopping test, run all sweeps of
  *                          a solve in one launch when its grid (one workgroup per 256 columns)
  *                          fits the chip's CUs; 0: one launch per sweep.
- *   ONMF_OPT_SPIN_LIMIT_MS bound, in milliseconds, of the waits of a one-launch solve's workgroups for each
- *                          other (default 2000; negative: give up at the first look, which exercises
- *                          the recovery path - every kernel still ends normally).  After a timeout the
- *                          solve is run again with one launch per sweep, and so are all later ones.
+ *   ONMF_OPT_SPIN_LIMIT_MS bound, in milliseconds, of the waits of workgroups for each other - a
+ *                          one-launch solve's, and the dictionary pass's for d > 1024 (default 2000;
+ *                          negative: give up at the first look, which exercises the recovery paths -
+ *                          every kernel still ends normally).  After a timeout the solve is run again
+ *                          with one launch per sweep, and so are the next 64 solves (128 after the next
+ *                          timeout, and so on); then the one-launch mode is tried again.  The one-launch
+ *                          mode assumes that one workgroup per CU is resident at once, which holds when
+ *                          the process has the GPU to itself; another process's kernels on the same GPU
+ *                          can break it, and these counters show when that happens.
  */
 #define ONMF_OPT_PROFILE 1
 #define ONMF_OPT_EXACT_STOP 2
@@ -252,6 +309,16 @@ double onmf_host_lambda_max(const float* S_host, int n);
 #define ONMF_OPT_PERSISTENT_SWEEPS 7
 #define ONMF_OPT_SPIN_LIMIT_MS 8
 int onmf_set_option(onmf_ctx* ctx, int key, int value);
+/*
+ * Event counters since onmf_create (no counterpart in the reference):
+ *   ONMF_CNT_SWEEP_TIMEOUTS   one-launch solves whose workgroups gave up waiting for each other
+ *   ONMF_CNT_DICT_TIMEOUTS    dictionary passes redone atom by atom for the same reason
+ *   ONMF_CNT_FALLBACK_SOLVES  solves that ran with one launch per sweep because of an earlier timeout
+ */
+#define ONMF_CNT_SWEEP_TIMEOUTS 1
+#define ONMF_CNT_DICT_TIMEOUTS 2
+#define ONMF_CNT_FALLBACK_SOLVES 3
+int onmf_get_counter(onmf_ctx* ctx, int which, long long* value);
 /* Summed device time (ms) and number of sweep-kernel launches since the previous call. */
 int onmf_get_profile(onmf_ctx* ctx, double* sweep_ms, int* sweep_launches);
 

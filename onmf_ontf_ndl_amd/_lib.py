@@ -23,6 +23,9 @@ OPT_SCREEN_STOP = 5
 OPT_DICT_KERNEL = 6
 OPT_PERSISTENT_SWEEPS = 7
 OPT_SPIN_LIMIT_MS = 8
+CNT_SWEEP_TIMEOUTS = 1
+CNT_DICT_TIMEOUTS = 2
+CNT_FALLBACK_SOLVES = 3
 NDL_GLAUBER = 0
 NDL_PIVOT = 1
 
@@ -41,10 +44,16 @@ SIGNATURES = {
     "onmf_aggregate": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, _f, C.c_int, _f, C.c_double,
                                  _f, _f, _f, _f, _f, _f, C.c_void_p]),
     "onmf_update_dict": (C.c_int, [_ctx, C.c_int, C.c_int, _f, _f, _f, _f, C.c_void_p]),
+    "onmf_update_dict_static": (C.c_int, [_ctx, C.c_int, C.c_int, _f, _f, _f, _f, C.c_void_p]),
     "onmf_step": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, _f, C.c_int, _f, _f, _f, _f, _f,
                             C.c_uint64, C.c_double, C.c_float, C.c_int, C.c_float,
                             _f, _f, _f, _f, _f, C.POINTER(C.c_int), C.POINTER(C.c_float),
                             C.c_void_p]),
+    "onmf_partial_floats": (C.c_size_t, [C.c_int, C.c_int]),
+    "onmf_step_partial": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, _f, C.c_int, _f, _f, _f, _f, C.c_uint64,
+                                    C.c_float, C.c_int, C.c_float, _f, _f, _f, C.POINTER(C.c_int),
+                                    C.POINTER(C.c_float), C.c_void_p, C.c_void_p]),
+    "onmf_step_apply": (C.c_int, [_ctx, C.c_int, C.c_int, _f, C.c_double, _f, _f, _f, _f, C.c_void_p]),
     "onmf_gather_columns": (C.c_int, [_ctx, C.c_int, C.c_int, _f, C.c_int, C.c_void_p, C.c_int, _f,
                                       C.c_void_p]),
     "onmf_code_accumulate": (C.c_int, [_ctx, C.c_int, C.c_int, _f, C.c_void_p, C.c_int, _f,
@@ -71,6 +80,7 @@ SIGNATURES = {
     "onmf_host_lambda_max": (C.c_double, [C.c_void_p, C.c_int]),
     "onmf_set_option": (C.c_int, [_ctx, C.c_int, C.c_int]),
     "onmf_get_profile": (C.c_int, [_ctx, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "onmf_get_counter": (C.c_int, [_ctx, C.c_int, C.POINTER(C.c_longlong)]),
 }
 
 _lib = None

@@ -184,6 +184,37 @@ double host_lambda_max(const float* S, int n) { return lambda_max_impl(S, n, 0.0
 // ---------------------------------------------------------------------------------------------
 // ABI
 // ---------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------
+// Static scratch of the entry point that allocates nothing (onmf_update_dict_static): the
+// dictionary pass's workspace for d <= 1024, r <= 256.  Every GPU the library runs on holds its own
+// copy of this array, at its own address, until the process ends; host code never uses the array's
+// name as an address - only what hipGetSymbolAddress returned for the device in question.
+// ---------------------------------------------------------------------------------------------
+constexpr int STATIC_DICT_MAX_D = 1024;
+constexpr int STATIC_DICT_MAX_R = 256;
+constexpr size_t STATIC_SCRATCH_FLOATS =
+    4 * (size_t)STATIC_DICT_MAX_D * STATIC_DICT_MAX_R + (size_t)STATIC_DICT_MAX_R * STATIC_DICT_MAX_R;   // 4.25 MB
+static __device__ __align__(256) float scratch[STATIC_SCRATCH_FLOATS];
+static float* g_scratch_ptr[LdsLimit::MAX_DEV];     // per device, filled by onmf_create
+
+// with `device` current
+static int static_scratch_for_device(int device, float** out) {
+    *out = nullptr;
+    if (device < 0 || device >= LdsLimit::MAX_DEV)
+        return onmf_fail(nullptr, ONMF_ERR_ARG, "device %d: the static scratch table covers %d devices", device,
+                         LdsLimit::MAX_DEV);
+    if (!g_scratch_ptr[device]) {
+        float* ptr = nullptr;
+        hipError_t e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !ptr)
+            return onmf_fail(nullptr, ONMF_ERR_HIP, "hipGetSymbolAddress(scratch) on device %d: %s", device,
+                             hipGetErrorString(e));
+        g_scratch_ptr[device] = ptr;
+    }
+    *out = g_scratch_ptr[device];
+    return ONMF_OK;
+}
+
 extern "C" {
 
 int onmf_abi_version(void) { return ONMF_ABI_VERSION; }
@@ -199,19 +230,23 @@ int onmf_create(int device, onmf_ctx** out) {
         return onmf_fail(nullptr, ONMF_ERR_HIP, "onmf_create: no HIP device (%s)", hipGetErrorString(e));
     if (device < 0 || device >= count)
         return onmf_fail(nullptr, ONMF_ERR_ARG, "onmf_create: device %d out of range (%d devices)", device, count);
-    e = hipSetDevice(device);
-    if (e != hipSuccess)
-        return onmf_fail(nullptr, ONMF_ERR_HIP, "hipSetDevice(%d): %s", device, hipGetErrorString(e));
+    DeviceGuard guard(device);
+    if (guard.err != hipSuccess)
+        return onmf_fail(nullptr, ONMF_ERR_HIP, "hipSetDevice(%d): %s", device, hipGetErrorString(guard.err));
+    float* sp = nullptr;
+    int rc = static_scratch_for_device(device, &sp);
+    if (rc != ONMF_OK) return rc;
     onmf_ctx* c = new (std::nothrow) onmf_ctx();
     if (!c) return onmf_fail(nullptr, ONMF_ERR_NOMEM, "onmf_create: out of host memory");
     c->device = device;
+    c->static_scratch = sp;
     *out = c;
     return ONMF_OK;
 }
 
 int onmf_destroy(onmf_ctx* c) {
     if (!c) return ONMF_OK;
-    (void)hipSetDevice(c->device);
+    DeviceGuard guard(c->device);
     (void)hipDeviceSynchronize();
     DevBuf* bufs[] = {&c->slab, &c->cm, &c->gram, &c->hbuf[0], &c->hbuf[1], &c->stats, &c->small,
                       &c->qt, &c->sync, &c->idx, &c->dbuf, &c->slab_side, &c->screen, &c->ddelta, &c->slab_prep};
@@ -242,7 +277,10 @@ int onmf_set_option(onmf_ctx* c, int key, int value) {
         case ONMF_OPT_OVERLAP_DICT: c->overlap_dict = value; return ONMF_OK;
         case ONMF_OPT_SCREEN_STOP: c->screen_stop = value; return ONMF_OK;
         case ONMF_OPT_DICT_KERNEL: c->dict_kernel = value; return ONMF_OK;
-        case ONMF_OPT_PERSISTENT_SWEEPS: c->persistent_sweeps = value; return ONMF_OK;
+        case ONMF_OPT_PERSISTENT_SWEEPS:
+            c->persistent_sweeps = value;
+            c->persistent_hold = 0;
+            return ONMF_OK;
         case ONMF_OPT_SPIN_LIMIT_MS:
             c->spin_limit = value < 0 ? -1LL : (long long)value * 100000LL;      // 100 MHz ticks
             return ONMF_OK;
@@ -250,8 +288,19 @@ int onmf_set_option(onmf_ctx* c, int key, int value) {
     }
 }
 
+int onmf_get_counter(onmf_ctx* c, int which, long long* value) {
+    if (!c || !value) return ONMF_ERR_ARG;
+    switch (which) {
+        case ONMF_CNT_SWEEP_TIMEOUTS: *value = c->n_sweep_timeouts; return ONMF_OK;
+        case ONMF_CNT_DICT_TIMEOUTS: *value = c->n_dict_timeouts; return ONMF_OK;
+        case ONMF_CNT_FALLBACK_SOLVES: *value = c->n_fallback_solves; return ONMF_OK;
+        default: return onmf_fail(c, ONMF_ERR_ARG, "onmf_get_counter: unknown counter %d", which);
+    }
+}
+
 int onmf_get_profile(onmf_ctx* c, double* sweep_ms, int* sweep_launches) {
     if (!c) return ONMF_ERR_ARG;
+    ONMF_ENTER(c);
     double total = 0.0;
     const int pairs = c->ev_used / 2;
     for (int i = 0; i < pairs; ++i) {
@@ -339,7 +388,6 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
     if (after_valid) *after_valid = false;
     if (d <= 0 || r <= 0 || b <= 0 || !X || !W || !H || ldx < b || sub_iter < 0)
         return onmf_fail(c, ONMF_ERR_ARG, "sparse_code: bad arguments (d=%d r=%d b=%d ldx=%d)", d, r, b, ldx);
-    HIP_TRY(c, hipSetDevice(c->device));
     const size_t rb = (size_t)r * b;
     ONMF_TRY(onmf_reserve(c, c->gram, (size_t)r * r * sizeof(float), "Gm"));
     ONMF_TRY(onmf_reserve(c, c->cm, rb * sizeof(float), "Cm"));
@@ -448,7 +496,13 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
             HIP_TRY(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
             c->cu_count = cus;
         }
-        const bool persistent = c->persistent_sweeps && sweep_tile_workgroups(b) <= c->cu_count;
+        // (after a timeout the one-launch mode rests for persistent_backoff solves, then gets another try)
+        const bool fits = sweep_tile_workgroups(b) <= c->cu_count;
+        if (fits && c->persistent_sweeps && c->persistent_hold > 0) {
+            --c->persistent_hold;
+            ++c->n_fallback_solves;
+        }
+        const bool persistent = c->persistent_sweeps && c->persistent_hold == 0 && fits && !second_try;
         int start = 0;
         while (start < sub_iter) {
             const ScreenDev sc = {base, start, (float)tol, (float)rank_cap, c->spin_limit /* 2 s */};
@@ -500,18 +554,23 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
                 if (code == 0) {
                     HIP_TRY(c, hipMemcpy(&done, base + ScreenLayout::FLAG, sizeof(int), hipMemcpyDeviceToHost));
                     if (done == SCREEN_FLAG_TIMEOUT) {
-                        // the grid was not resident as a whole (CUs taken or masked): from now on one launch
-                        // per sweep, which needs no co-residency - starting with this very solve, if its
-                        // start can be had again (drawn from the seed, or still in the caller's H0)
-                        c->persistent_sweeps = 0;
+                        // the grid was not resident as a whole (CUs taken or masked): one launch per sweep,
+                        // which needs no co-residency, for this very solve (if its start can be had again:
+                        // drawn from the seed, or still in the caller's H0) and for the next
+                        // persistent_backoff solves; the one-launch mode is then tried again
+                        ++c->n_sweep_timeouts;
+                        c->persistent_backoff = c->persistent_backoff ? std::min(c->persistent_backoff * 2, 1 << 20) : 64;
+                        c->persistent_hold = c->persistent_backoff;
+                        c->err = "sparse_code: a sweep workgroup gave up waiting for the others (grid not resident "
+                                 "as a whole?); solves run with one launch per sweep for a while";
                         const bool start_intact = H0 == nullptr || (H0 != buf[0] && H0 != buf[1] && H0 != buf[2]);
                         if (!second_try && start_intact)
                             return sparse_code_impl(c, d, r, b, X, ldx, W, H0, seed, alpha, sub_iter, stopping_diff,
                                                     coder_mode, H, sweeps_done, dist_trace, s, after, after_valid, true,
                                                     behind_sweeps);
                         return onmf_fail(c, ONMF_ERR_TIMEOUT,
-                                         "sparse_code: a sweep workgroup waited more than 2 s for the others; "
-                                         "later solves use one launch per sweep");
+                                         "sparse_code: a sweep workgroup gave up waiting for the others and the "
+                                         "solve's start is gone; later solves use one launch per sweep for a while");
                     }
                     return onmf_fail(c, ONMF_ERR_HIP, "sparse_code: sweep %d left no verdict", i);
                 }
@@ -560,12 +619,19 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
         }
     } else {
         double dist = 1.0;      // src/onmf.py:251
+        // Exact coordinate descent runs to a fixed point, typically hundreds of sweeps: they go in
+        // chunks of several sweeps per launch (8, 16, 32, 64, 64, ...) and the relative change is
+        // tested on the last sweep of each chunk - one host round trip per chunk instead of per sweep.
+        const bool chunked = exact_cd && sweep_tile_covers(r, b) && c->sweep_kernel != 1;
+        int chunk = 8;
         while (done < sub_iter && keep_sweeping(dist, tol)) {
-            float* cur = buf[done % 3];
-            float* nxt = buf[(done + 1) % 3];
+            const int count = chunked ? std::min(chunk, sub_iter - done) : 1;
+            chunk = std::min(64, chunk * 2);
+            float* cur = buf[(done + count - 1) % 3];
+            float* nxt = buf[(done + count) % 3];
             int groups = 0;
             ONMF_TRY(profile_mark(c, s));
-            ONMF_TRY(launch_sweep(c, r, b, Gm, Cm, buf, alpha, exact_cd, done, 1, (double*)c->stats.p, &groups, s));
+            ONMF_TRY(launch_sweep(c, r, b, Gm, Cm, buf, alpha, exact_cd, done, count, (double*)c->stats.p, &groups, s));
             ONMF_TRY(profile_mark(c, s));
             HIP_TRY(c, hipMemcpyAsync(c->pinned, c->stats.p, (size_t)groups * 2 * sizeof(double),
                                       hipMemcpyDeviceToHost, s));
@@ -576,6 +642,9 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
                 dsum += hs[2 * g];
                 hsum += hs[2 * g + 1];
             }
+            if (dist_trace)
+                for (int i = done; i + 1 < done + count; ++i) dist_trace[i] = (float)nan;   // not evaluated
+            done += count - 1;      // (the statistics are those of the chunk's last sweep)
             // Decide `dist > tol` from Frobenius norms when they settle it:
             //   s1 in [fD / sqrt(rank), fD],  s0 in [fH / sqrt(rank), fH]   (fD, fH Frobenius norms)
             bool decided = false;
@@ -627,7 +696,6 @@ static int aggregate_impl(onmf_ctx* c, int d, int r, int b, const float* X, int 
                           float* A_out, float* B_out, float* C_out, hipStream_t s) {
     if (d <= 0 || r <= 0 || b <= 0 || !X || !H || !A_out || !B_out || ldx < b)
         return onmf_fail(c, ONMF_ERR_ARG, "aggregate: bad arguments");
-    HIP_TRY(c, hipSetDevice(c->device));
     const float fw = (float)w, keep = (float)(1.0 - w);
     // A_out = (1-w) A_in + w H H^T ; B_out = (1-w) B_in + w H X^T   (src/onmf.py:155-156)
     ONMF_TRY(launch_gemm_nt_pair(c, r, b, H, b, H, b, r, X, ldx, d, fw, A_in ? keep : 0.f, A_in, A_out, r,
@@ -637,16 +705,35 @@ static int aggregate_impl(onmf_ctx* c, int d, int r, int b, const float* X, int 
     return ONMF_OK;
 }
 
-static int dict_check(onmf_ctx* c, int r, int d, hipStream_t s) {
+// After a dictionary pass whose workgroups wait for each other (d > 1024): read its timeout flag.
+// If a workgroup gave up (the grid was not resident as a whole), the pass is done again without any
+// waiting between workgroups (launch_dict_pass_serial), from W_in if that is still intact (W_out is
+// another buffer) or from the transposed copy the panel kernel's head staged.  Synchronises s.
+static int dict_check(onmf_ctx* c, int d, int r, const float* W_in, const float* A, const float* B, float* W_out,
+                      hipStream_t s) {
     if (!c->dict_coop_last) return ONMF_OK;
     const size_t off = c->dict_flag_off;
     ONMF_TRY(onmf_reserve_pinned(c, 64));
     HIP_TRY(c, hipMemcpyAsync(c->pinned, (char*)c->sync.p + off, sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
-    if (*(int*)c->pinned != 0)
-        return onmf_fail(c, ONMF_ERR_TIMEOUT,
-                         "update_dict: a workgroup waited more than 2 s for the others (not co-resident?)");
-    return ONMF_OK;
+    if (*(int*)c->pinned == 0) return ONMF_OK;
+    ++c->n_dict_timeouts;
+    c->dict_coop_last = false;
+    const float* src = W_in;
+    if (W_in == W_out) {
+        // in place: the caller's W went with the discarded result; the head kernel's transposed copy
+        // is intact (the panel kernel only reads it)
+        const float* wt = c->dict_kernel != 1 ? dict_staged_wt(c, d, r) : nullptr;
+        if (!wt)
+            return onmf_fail(c, ONMF_ERR_TIMEOUT,
+                             "update_dict: a workgroup gave up waiting for the others (not co-resident?) and the "
+                             "in-place input is gone");
+        ONMF_TRY(launch_transpose(r, d, wt, W_out, s));
+        src = W_out;
+    }
+    c->err = "update_dict: a workgroup gave up waiting for the others (not co-resident?); the pass was redone "
+             "atom by atom";
+    return launch_dict_pass_serial(c, d, r, src, A, B, W_out, s);
 }
 
 extern "C" {
@@ -656,6 +743,7 @@ int onmf_sparse_code(onmf_ctx* c, int d, int r, int b, const float* X, int ldx, 
                      int coder_mode, float* H, int* sweeps_done, float* dist_trace, void* stream) {
     if (!c) return ONMF_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
+    ONMF_ENTER(c);
     ONMF_TRY(sparse_code_impl(c, d, r, b, X, ldx, W, H0, seed, alpha, sub_iter, stopping_diff,
                               coder_mode, H, sweeps_done, dist_trace, s));
     HIP_TRY(c, hipStreamSynchronize(s));
@@ -666,6 +754,7 @@ int onmf_aggregate(onmf_ctx* c, int d, int r, int b, const float* X, int ldx, co
                    const float* A_in, const float* B_in, const float* C_in, float* A_out, float* B_out,
                    float* C_out, void* stream) {
     if (!c) return ONMF_ERR_ARG;
+    ONMF_ENTER(c);
     return aggregate_impl(c, d, r, b, X, ldx, H, w, A_in, B_in, C_in, A_out, B_out, C_out,
                           (hipStream_t)stream);
 }
@@ -676,28 +765,46 @@ int onmf_update_dict(onmf_ctx* c, int d, int r, const float* W_in, const float* 
     if (d <= 0 || r <= 0 || !W_in || !A || !B || !W_out)
         return onmf_fail(c, ONMF_ERR_ARG, "update_dict: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    HIP_TRY(c, hipSetDevice(c->device));
+    ONMF_ENTER(c);
     ONMF_TRY(launch_dict_pass(c, d, r, W_in, A, B, W_out, s));
-    return dict_check(c, r, d, s);
+    return dict_check(c, d, r, W_in, A, B, W_out, s);
 }
 
-int onmf_step(onmf_ctx* c, int d, int r, int b, const float* X, int ldx, const float* W_in,
-              const float* A_in, const float* B_in, const float* C_in, const float* H0, uint64_t seed,
-              double w, float alpha, int sub_iter, float stopping_diff, float* H_out, float* A_out,
-              float* B_out, float* C_out, float* W_out, int* sweeps_done, float* dist_trace,
-              void* stream) {
+int onmf_update_dict_static(onmf_ctx* c, int d, int r, const float* W_in, const float* A, const float* B,
+                            float* W_out, void* stream) {
     if (!c) return ONMF_ERR_ARG;
-    if (!W_in || !A_in || !B_in || !A_out || !B_out || !W_out)
-        return onmf_fail(c, ONMF_ERR_ARG, "step: null state pointer");
-    hipStream_t s = (hipStream_t)stream;
-    HIP_TRY(c, hipSetDevice(c->device));
+    if (d <= 0 || r <= 0 || !W_in || !A || !B || !W_out)
+        return onmf_fail(c, ONMF_ERR_ARG, "update_dict_static: bad arguments");
+    if (d > STATIC_DICT_MAX_D || r > STATIC_DICT_MAX_R || dict_workspace_floats(d, r) > STATIC_SCRATCH_FLOATS)
+        return onmf_fail(c, ONMF_ERR_ARG,
+                         "update_dict_static: d=%d r=%d exceed the static scratch (d <= %d, r <= %d); use "
+                         "onmf_update_dict", d, r, STATIC_DICT_MAX_D, STATIC_DICT_MAX_R);
+    if (!c->static_scratch) return onmf_fail(c, ONMF_ERR_HIP, "update_dict_static: no static scratch on this device");
+    ONMF_ENTER(c);
+    // one workgroup does the whole pass (d <= 1024): no waits between workgroups, no flag to read back,
+    // nothing to clear - the head kernel rewrites every part of the workspace the pass reads
+    return launch_dict_pass(c, d, r, W_in, A, B, W_out, (hipStream_t)stream, 0, c->static_scratch);
+}
+
+}  // extern "C"
+
+// One step (src/onmf.py:119-167).  The dictionary pass reads (W_in, dA, dB) - the aggregates from
+// BEFORE the step (onmf.py:161); the aggregate recursion starts from (gA, gB, gC) with weight w and
+// writes (A_out, B_out, C_out).  onmf_step passes the same aggregates to both; onmf_step_partial
+// passes none to the recursion (bare sums).  `gate` (optional): an event the dictionary pass and the
+// aggregate products wait for - the code solve does not.
+static int step_impl(onmf_ctx* c, int d, int r, int b, const float* X, int ldx, const float* W_in,
+                     const float* dA, const float* dB, const float* gA, const float* gB, const float* gC,
+                     const float* H0, uint64_t seed, double w, float alpha, int sub_iter, float stopping_diff,
+                     float* H_out, float* A_out, float* B_out, float* C_out, float* W_out, int* sweeps_done,
+                     float* dist_trace, hipStream_t s, hipEvent_t gate) {
     float* H = H_out;
     if (!H) {
         // hbuf[] are the sweep ping-pong buffers, so the code gets its own scratch
         ONMF_TRY(onmf_reserve(c, c->dbuf, (size_t)r * b * sizeof(float) * 2, "step code"));
         H = (float*)c->dbuf.p + (size_t)r * b;
     }
-    const bool aliased = (W_out == W_in) || (A_out == A_in) || (B_out == B_in);
+    const bool aliased = (W_out == W_in) || (A_out == dA) || (B_out == dB);
     if (c->overlap_dict && !aliased) {
         // The dictionary pass reads only W_in and the OLD aggregates (src/onmf.py:161), so it is
         // independent of this step's code and runs on a second stream (default priority) beside it.
@@ -708,6 +815,7 @@ int onmf_step(onmf_ctx* c, int d, int r, int b, const float* X, int ldx, const f
         }
         HIP_TRY(c, hipEventRecord(c->ev_fork, s));
         HIP_TRY(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
+        if (gate) HIP_TRY(c, hipStreamWaitEvent(c->side, gate, 0));
         // The pass is one workgroup per 1024 rows that claims its CU whole, so it cannot run beside the
         // sweeps (one workgroup per CU, all of them needed at once).  It runs in two parts: the first
         // atoms beside W^T X, the rest beside the aggregate products - posted right behind the sweeps,
@@ -715,7 +823,7 @@ int onmf_step(onmf_ctx* c, int d, int r, int b, const float* X, int ldx, const f
         // the chip (arriving after them it waits for one of their workgroups to end: most of their
         // duration).
         const bool split = dict_pass_splits(c, d, r);
-        int rc = launch_dict_pass(c, d, r, W_in, A_in, B_in, W_out, c->side, split ? 1 : 0);
+        int rc = launch_dict_pass(c, d, r, W_in, dA, dB, W_out, c->side, split ? 1 : 0);
         int rc2 = ONMF_OK;
         bool agg_done = false, second_posted = !split;
         const std::function<int()> post_dict = [&]() {
@@ -724,11 +832,12 @@ int onmf_step(onmf_ctx* c, int d, int r, int b, const float* X, int ldx, const f
             if (!c->ev_mid) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_mid, hipEventDisableTiming));
             HIP_TRY(c, hipEventRecord(c->ev_mid, s));                 // behind the sweeps
             HIP_TRY(c, hipStreamWaitEvent(c->side, c->ev_mid, 0));
-            return launch_dict_pass(c, d, r, W_in, A_in, B_in, W_out, c->side, 2);
+            return launch_dict_pass(c, d, r, W_in, dA, dB, W_out, c->side, 2);
         };
         const std::function<int()> agg = [&]() {
             ONMF_TRY(post_dict());
-            return aggregate_impl(c, d, r, b, X, ldx, H, w, A_in, B_in, C_in, A_out, B_out, C_out, s);
+            if (gate) HIP_TRY(c, hipStreamWaitEvent(s, gate, 0));
+            return aggregate_impl(c, d, r, b, X, ldx, H, w, gA, gB, gC, A_out, B_out, C_out, s);
         };
         if (rc == ONMF_OK)
             rc2 = sparse_code_impl(c, d, r, b, X, ldx, W_in, H0, seed, alpha, sub_iter, stopping_diff,
@@ -741,15 +850,66 @@ int onmf_step(onmf_ctx* c, int d, int r, int b, const float* X, int ldx, const f
         if (rc2 != ONMF_OK) return rc2;
         HIP_TRY(c, e1);
         HIP_TRY(c, e2);
-        return dict_check(c, r, d, s);
+        return dict_check(c, d, r, W_in, dA, dB, W_out, s);
     }
     // serial order keeps every in-place aliasing legal: code (reads W_in) -> dictionary pass with
-    // the OLD aggregates -> aggregates
+    // the OLD aggregates (checked before they are overwritten) -> aggregates
     ONMF_TRY(sparse_code_impl(c, d, r, b, X, ldx, W_in, H0, seed, alpha, sub_iter, stopping_diff,
                               ONMF_CODER_DAMPED, H, sweeps_done, dist_trace, s));
-    ONMF_TRY(launch_dict_pass(c, d, r, W_in, A_in, B_in, W_out, s));
-    ONMF_TRY(aggregate_impl(c, d, r, b, X, ldx, H, w, A_in, B_in, C_in, A_out, B_out, C_out, s));
-    return dict_check(c, r, d, s);
+    if (gate) HIP_TRY(c, hipStreamWaitEvent(s, gate, 0));
+    ONMF_TRY(launch_dict_pass(c, d, r, W_in, dA, dB, W_out, s));
+    ONMF_TRY(dict_check(c, d, r, W_in, dA, dB, W_out, s));
+    return aggregate_impl(c, d, r, b, X, ldx, H, w, gA, gB, gC, A_out, B_out, C_out, s);
+}
+
+extern "C" {
+
+int onmf_step(onmf_ctx* c, int d, int r, int b, const float* X, int ldx, const float* W_in,
+              const float* A_in, const float* B_in, const float* C_in, const float* H0, uint64_t seed,
+              double w, float alpha, int sub_iter, float stopping_diff, float* H_out, float* A_out,
+              float* B_out, float* C_out, float* W_out, int* sweeps_done, float* dist_trace,
+              void* stream) {
+    if (!c) return ONMF_ERR_ARG;
+    if (!W_in || !A_in || !B_in || !A_out || !B_out || !W_out)
+        return onmf_fail(c, ONMF_ERR_ARG, "step: null state pointer");
+    ONMF_ENTER(c);
+    return step_impl(c, d, r, b, X, ldx, W_in, A_in, B_in, A_in, B_in, C_in, H0, seed, w, alpha, sub_iter,
+                     stopping_diff, H_out, A_out, B_out, C_out, W_out, sweeps_done, dist_trace,
+                     (hipStream_t)stream, nullptr);
+}
+
+size_t onmf_partial_floats(int d, int r) { return (((size_t)r * r + 3) & ~(size_t)3) + (size_t)r * d; }
+
+int onmf_step_partial(onmf_ctx* c, int d, int r, int b, const float* X, int ldx, const float* W_in,
+                      const float* A_in, const float* B_in, const float* H0, uint64_t seed, float alpha,
+                      int sub_iter, float stopping_diff, float* H_out, float* P_out, float* W_out,
+                      int* sweeps_done, float* dist_trace, void* state_ready_event, void* stream) {
+    if (!c) return ONMF_ERR_ARG;
+    if (!W_in || !A_in || !B_in || !P_out || !W_out)
+        return onmf_fail(c, ONMF_ERR_ARG, "step_partial: null state pointer");
+    if (d <= 0 || r <= 0) return onmf_fail(c, ONMF_ERR_ARG, "step_partial: bad shape");
+    ONMF_ENTER(c);
+    float* HHt = P_out;
+    float* HXt = P_out + (((size_t)r * r + 3) & ~(size_t)3);
+    return step_impl(c, d, r, b, X, ldx, W_in, A_in, B_in, nullptr, nullptr, nullptr, H0, seed, 1.0, alpha, sub_iter,
+                     stopping_diff, H_out, HHt, HXt, nullptr, W_out, sweeps_done, dist_trace, (hipStream_t)stream,
+                     (hipEvent_t)state_ready_event);
+}
+
+int onmf_step_apply(onmf_ctx* c, int d, int r, const float* P, double w, const float* A_in, const float* B_in,
+                    float* A_out, float* B_out, void* stream) {
+    if (!c) return ONMF_ERR_ARG;
+    if (d <= 0 || r <= 0 || !P || !A_in || !B_in || !A_out || !B_out)
+        return onmf_fail(c, ONMF_ERR_ARG, "step_apply: bad arguments");
+    ONMF_ENTER(c);
+    hipStream_t s = (hipStream_t)stream;
+    const float fw = (float)w, keep = (float)(1.0 - w);
+    const float* HHt = P;
+    const float* HXt = P + (((size_t)r * r + 3) & ~(size_t)3);
+    if (launch_axpby(A_out, A_in, keep, HHt, fw, (size_t)r * r, s) != ONMF_OK ||
+        launch_axpby(B_out, B_in, keep, HXt, fw, (size_t)r * d, s) != ONMF_OK)
+        return onmf_fail(c, ONMF_ERR_HIP, "step_apply: launch failed");
+    return ONMF_OK;
 }
 
 int onmf_gather_columns(onmf_ctx* c, int d, int n, const float* X, int ldx, const int64_t* idx, int b,
@@ -757,7 +917,7 @@ int onmf_gather_columns(onmf_ctx* c, int d, int n, const float* X, int ldx, cons
     if (!c) return ONMF_ERR_ARG;
     if (d <= 0 || n <= 0 || b <= 0 || !X || !idx || !Xb || ldx < n)
         return onmf_fail(c, ONMF_ERR_ARG, "gather_columns: bad arguments");
-    HIP_TRY(c, hipSetDevice(c->device));
+    ONMF_ENTER(c);
     if (launch_gather_columns(d, n, X, ldx, (const long long*)idx, b, Xb, (hipStream_t)stream) != ONMF_OK)
         return onmf_fail(c, ONMF_ERR_HIP, "gather_columns: launch failed");
     return ONMF_OK;
@@ -768,7 +928,7 @@ int onmf_code_accumulate(onmf_ctx* c, int r, int n, float* code, const int64_t* 
     if (!c) return ONMF_ERR_ARG;
     if (r <= 0 || n <= 0 || b <= 0 || !code || !H || (!idx && b != n))
         return onmf_fail(c, ONMF_ERR_ARG, "code_accumulate: bad arguments");
-    HIP_TRY(c, hipSetDevice(c->device));
+    ONMF_ENTER(c);
     hipStream_t s = (hipStream_t)stream;
     if (!idx) {
         if (launch_axpy(code, H, 1.0f, (size_t)r * n, s) != ONMF_OK)
@@ -783,7 +943,7 @@ int onmf_unfold3(onmf_ctx* c, int n0, int n1, int n2, const float* T, int mode, 
     if (!c) return ONMF_ERR_ARG;
     if (n0 <= 0 || n1 <= 0 || n2 <= 0 || !T || !out || mode < 0 || mode > 2)
         return onmf_fail(c, ONMF_ERR_ARG, "unfold3: bad arguments");
-    HIP_TRY(c, hipSetDevice(c->device));
+    ONMF_ENTER(c);
     if (launch_unfold3(n0, n1, n2, T, mode, transpose, out, (hipStream_t)stream) != ONMF_OK)
         return onmf_fail(c, ONMF_ERR_HIP, "unfold3: launch failed");
     return ONMF_OK;
@@ -796,7 +956,7 @@ int onmf_sparse_code_each(onmf_ctx* c, int d, int r, int b, const float* X, int 
     if (d <= 0 || r <= 0 || b <= 0 || !X || !W || !H || ldx < b || sub_iter < 0)
         return onmf_fail(c, ONMF_ERR_ARG, "sparse_code_each: bad arguments (d=%d r=%d b=%d ldx=%d)", d, r, b, ldx);
     hipStream_t s = (hipStream_t)stream;
-    HIP_TRY(c, hipSetDevice(c->device));
+    ONMF_ENTER(c);
     const size_t rb = (size_t)r * b;
     ONMF_TRY(onmf_reserve(c, c->gram, (size_t)r * r * sizeof(float), "Gm"));
     ONMF_TRY(onmf_reserve(c, c->cm, rb * sizeof(float), "Cm"));
@@ -824,7 +984,7 @@ int onmf_patch_product(onmf_ctx* c, int d, int r, int b, const float* W, const f
     if (!c) return ONMF_ERR_ARG;
     if (d <= 0 || r <= 0 || b <= 0 || !W || !H || !R || ldr < b)
         return onmf_fail(c, ONMF_ERR_ARG, "patch_product: bad arguments");
-    HIP_TRY(c, hipSetDevice(c->device));
+    ONMF_ENTER(c);
     return launch_gemm(c, false, true, d, b, r, W, r, H, b, 1.f, 0.f, nullptr, R, ldr, (hipStream_t)stream);
 }
 
@@ -850,7 +1010,7 @@ int onmf_extract_patches(onmf_ctx* c, const float* img, int h, int w, int ch, in
     ONMF_TRY(patch_args(c, "extract_patches", h, w, ch, k, grid_rows, grid_cols, stride));
     if (!corners && (long long)grid_rows * grid_cols != b)
         return onmf_fail(c, ONMF_ERR_ARG, "extract_patches: b=%d is not the grid's %d x %d", b, grid_rows, grid_cols);
-    HIP_TRY(c, hipSetDevice(c->device));
+    ONMF_ENTER(c);
     if (launch_patch_extract(img, h, w, ch, k, (const int*)corners, b, corners ? 1 : grid_cols, corners ? 1 : stride,
                              X, ldx, (hipStream_t)stream) != ONMF_OK)
         return onmf_fail(c, ONMF_ERR_HIP, "extract_patches: launch failed");
@@ -863,7 +1023,7 @@ int onmf_fold_patches(onmf_ctx* c, const float* R, int ldr, int h, int w, int ch
     if (!R || !out || grid_rows <= 0 || grid_cols <= 0 || (long long)grid_rows * grid_cols > ldr)
         return onmf_fail(c, ONMF_ERR_ARG, "fold_patches: bad arguments");
     ONMF_TRY(patch_args(c, "fold_patches", h, w, ch, k, grid_rows, grid_cols, stride));
-    HIP_TRY(c, hipSetDevice(c->device));
+    ONMF_ENTER(c);
     if (launch_patch_fold(R, ldr, h, w, ch, k, grid_rows, grid_cols, stride, out, count, (hipStream_t)stream) !=
         ONMF_OK)
         return onmf_fail(c, ONMF_ERR_HIP, "fold_patches: launch failed");
@@ -875,7 +1035,7 @@ int onmf_surrogate_loss(onmf_ctx* c, int d, int r, const float* W, const float* 
     if (!c) return ONMF_ERR_ARG;
     if (d <= 0 || r <= 0 || !W || !A || !B || !loss) return onmf_fail(c, ONMF_ERR_ARG, "surrogate_loss: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    HIP_TRY(c, hipSetDevice(c->device));
+    ONMF_ENTER(c);
     constexpr int BLOCKS = 64;
     ONMF_TRY(onmf_reserve(c, c->qt, (size_t)r * d * sizeof(float), "W A"));
     ONMF_TRY(onmf_reserve(c, c->stats, BLOCKS * sizeof(double), "loss partials"));
@@ -905,7 +1065,7 @@ int onmf_ndl_init_embeddings(onmf_ctx* c, int n_nodes, const int32_t* row_ptr, c
                              int32_t* emb, void* stream) {
     if (!c) return ONMF_ERR_ARG;
     ONMF_TRY(ndl_args(c, "ndl_init_embeddings", n_nodes, row_ptr, nbr, k, motif, n_chains, emb));
-    HIP_TRY(c, hipSetDevice(c->device));
+    ONMF_ENTER(c);
     if (launch_ndl_chains(n_nodes, row_ptr, nbr, k, motif, 2, n_chains, 0, emb, pivots, seed, 0, nullptr, 0, nullptr,
                           (hipStream_t)stream) != ONMF_OK)
         return onmf_fail(c, ONMF_ERR_HIP, "ndl_init_embeddings: launch failed");
@@ -923,7 +1083,7 @@ int onmf_ndl_sample_patches(onmf_ctx* c, int n_nodes, const int32_t* row_ptr, co
     if (steps <= 0 || !X || (long long)n_chains * steps > ldx)
         return onmf_fail(c, ONMF_ERR_ARG, "ndl_sample_patches: %d chains x %d steps do not fit ldx=%d", n_chains, steps,
                          ldx);
-    HIP_TRY(c, hipSetDevice(c->device));
+    ONMF_ENTER(c);
     if (launch_ndl_chains(n_nodes, row_ptr, nbr, k, motif, chain_kind, n_chains, steps, emb, nullptr, seed, step_offset,
                           X, ldx, emb_trace, (hipStream_t)stream) != ONMF_OK)
         return onmf_fail(c, ONMF_ERR_HIP, "ndl_sample_patches: launch failed");
@@ -935,7 +1095,7 @@ int onmf_ndl_accumulate_edges(onmf_ctx* c, int n_nodes, int k, int n_patches, co
     if (!c) return ONMF_ERR_ARG;
     if (n_nodes <= 0 || k < 1 || k > 64 || n_patches <= 0 || !emb_trace || !R || !sum || !count || ldr < n_patches)
         return onmf_fail(c, ONMF_ERR_ARG, "ndl_accumulate_edges: bad arguments");
-    HIP_TRY(c, hipSetDevice(c->device));
+    ONMF_ENTER(c);
     if (launch_ndl_edge_accumulate(n_nodes, k, n_patches, emb_trace, R, ldr, sum, count, (hipStream_t)stream) != ONMF_OK)
         return onmf_fail(c, ONMF_ERR_HIP, "ndl_accumulate_edges: launch failed");
     return ONMF_OK;
@@ -944,7 +1104,7 @@ int onmf_ndl_accumulate_edges(onmf_ctx* c, int n_nodes, int k, int n_patches, co
 int onmf_fill_uniform(onmf_ctx* c, float* out, size_t n, uint64_t seed, void* stream) {
     if (!c) return ONMF_ERR_ARG;
     if (!out && n) return onmf_fail(c, ONMF_ERR_ARG, "fill_uniform: null output");
-    HIP_TRY(c, hipSetDevice(c->device));
+    ONMF_ENTER(c);
     if (launch_fill_uniform(out, n, seed, (hipStream_t)stream) != ONMF_OK)
         return onmf_fail(c, ONMF_ERR_HIP, "fill_uniform: launch failed");
     return ONMF_OK;

@@ -64,7 +64,38 @@ struct onmf_ctx {
     int dict_kernel = 0;            // 0 = by shape, 1 = cooperative workgroups, 2 = one workgroup
     size_t dict_flag_off = 0;       // byte offset of that flag in `sync`
     bool dict_coop_last = false;    // the last dictionary pass used the cooperative kernel (its timeout flag is live)
+    // one-launch solves after a timeout: how many solves run with one launch per sweep before the
+    // one-launch mode is tried again (doubles at every timeout), and how many of them are left
+    int persistent_backoff = 0;
+    int persistent_hold = 0;
+    long long n_sweep_timeouts = 0;       // solves whose workgroups gave up waiting for each other
+    long long n_dict_timeouts = 0;        // dictionary passes whose workgroups gave up waiting for each other
+    long long n_fallback_solves = 0;      // solves run with one launch per sweep because of an earlier timeout
+    float* static_scratch = nullptr;      // this device's copy of the library's static scratch array
 };
+
+// Makes the context's device current for the duration of an entry point and puts the caller's back
+// on the way out (the caller may be driving another GPU from the same thread).
+struct DeviceGuard {
+    int prev = -1;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int device) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != device) err = hipSetDevice(device);
+        else if (err != hipSuccess) prev = -1;
+        if (prev == device) prev = -1;            // nothing to restore
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define ONMF_ENTER(ctx)                                                                          \
+    DeviceGuard _device_guard((ctx)->device);                                                    \
+    if (_device_guard.err != hipSuccess)                                                         \
+        return onmf_fail((ctx), ONMF_ERR_HIP, "selecting device %d failed: %s", (ctx)->device,   \
+                         hipGetErrorString(_device_guard.err))
 
 int onmf_fail(onmf_ctx* c, int code, const char* fmt, ...);
 int onmf_reserve(onmf_ctx* c, DevBuf& b, size_t bytes, const char* what);
@@ -307,9 +338,20 @@ int launch_screen_cw(onmf_ctx* c, float* base, int r, int b, const float* H, int
 
 // part 0: the whole pass.  Parts 1 and 2 (dict_pass_splits): the first panels of atoms / the rest,
 // as two launches with the same arguments; W_out is complete after part 2.
+// `ws` (optional): caller-provided workspace of dict_workspace_floats(d, r) floats, 256-byte aligned,
+// for the one-workgroup form (d <= 1024); the context's own buffers are then left alone and nothing
+// is allocated.
 int launch_dict_pass(onmf_ctx* c, int d, int r, const float* Win, const float* A, const float* B,
-                     float* Wout, hipStream_t s, int part = 0);
+                     float* Wout, hipStream_t s, int part = 0, float* ws = nullptr);
 bool dict_pass_splits(const onmf_ctx* c, int d, int r);
+size_t dict_workspace_floats(int d, int r);
+// The pass without any waiting between workgroups: two small launches per atom.  Slow (r round trips
+// through the launch queue) but needs no co-residency: what a pass is redone with after its
+// workgroups gave up waiting for each other.  Wout may be Win.
+int launch_dict_pass_serial(onmf_ctx* c, int d, int r, const float* Win, const float* A, const float* B,
+                            float* Wout, hipStream_t s);
+// W^T as the last panel-kernel pass staged it (valid after launch_dict_pass on the panel path)
+const float* dict_staged_wt(const onmf_ctx* c, int d, int r);
 
 int launch_fill_uniform(float* out, size_t n, uint64_t seed, hipStream_t s);
 int launch_gather_columns(int d, int n, const float* X, int ldx, const long long* idx, int b,
@@ -318,6 +360,7 @@ int launch_scatter_add_last(onmf_ctx* c, int r, int n, float* code, const long l
                             const float* H, hipStream_t s);
 int launch_axpy(float* y, const float* x, float a, size_t n, hipStream_t s);
 int launch_sub(float* out, const float* a, const float* b, size_t n, hipStream_t s);
+int launch_axpby(float* out, const float* old, float keep, const float* part, float w, size_t n, hipStream_t s);
 int launch_unfold3(int n0, int n1, int n2, const float* T, int mode, int transpose, float* out,
                    hipStream_t s);
 int launch_transpose(int rows, int cols, const float* in, float* out, hipStream_t s);

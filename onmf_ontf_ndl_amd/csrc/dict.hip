@@ -499,16 +499,88 @@ __global__ void zero_u64_kernel(u64* p, size_t n) {
         p[i] = 0ull;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The pass with no waiting between workgroups: per atom j one launch that forms
+//     u = max(0, W[:,j] - (W A[:,j] - B[j,:]^T) / (A[j,j] + 1))
+// from the current W (rows are independent: one thread per row, the row's r entries of W against
+// column j of A) and leaves one partial sum of squares per workgroup, and a second launch that adds
+// the partials in a fixed order and writes W[:,j] = u / max(1, ||u||).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dict_atom_move_kernel(int d, int r, int j, const float* __restrict__ W,
+                                                             const float* __restrict__ A,
+                                                             const float* __restrict__ B, float* __restrict__ u,
+                                                             float* __restrict__ partial) {
+    __shared__ float red[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float v = 0.f;
+    if (i < d) {
+        const float* __restrict__ wrow = W + (size_t)i * r;
+        float dot = 0.f;
+        for (int k = 0; k < r; ++k) dot = fmaf(wrow[k], A[(size_t)k * r + j], dot);
+        const float inv = 1.0f / (A[(size_t)j * r + j] + 1.0f);
+        v = fmaxf(wrow[j] - (dot - B[(size_t)j * d + i]) * inv, 0.f);
+        u[i] = v;
+    }
+    const float ws = wave_sum(v * v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ws;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void dict_atom_scale_kernel(int d, int r, int j, float* __restrict__ W,
+                                                              const float* __restrict__ u,
+                                                              const float* __restrict__ partial, int nparts) {
+    float total = 0.f;
+    for (int p = 0; p < nparts; ++p) total += partial[p];      // same order in every thread
+    const float scale = 1.0f / fmaxf(1.0f, sqrtf(total));
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < d) W[(size_t)i * r + j] = u[i] * scale;
+}
+
 }  // namespace
 
 bool dict_pass_splits(const onmf_ctx* c, int d, int r) { return d <= 16 * 1024 && c->dict_kernel != 1 && r >= 32; }
 
+static inline size_t up64(size_t n) { return (n + 63) & ~(size_t)63; }
+
+// Qt | Ap | Dt | Wt | WtOut, every part starting on a 256-byte boundary
+size_t dict_workspace_floats(int d, int r) {
+    const size_t lda = (size_t)(r + 15) / 16 * 16;
+    return 4 * up64((size_t)d * r) + up64((size_t)r * lda);
+}
+
+const float* dict_staged_wt(const onmf_ctx* c, int d, int r) {
+    const size_t lda = (size_t)(r + 15) / 16 * 16;
+    if (!c->ddelta.p || c->ddelta.bytes < (3 * (size_t)d * r + (size_t)r * lda + 16) * sizeof(float)) return nullptr;
+    return (const float*)c->ddelta.p + (size_t)r * lda + (size_t)d * r;
+}
+
+int launch_dict_pass_serial(onmf_ctx* c, int d, int r, const float* Win, const float* A, const float* B,
+                            float* Wout, hipStream_t s) {
+    const int nparts = (d + 255) / 256;
+    ONMF_TRY(onmf_reserve(c, c->small, ((size_t)d + nparts + 2 * (size_t)r * r) * sizeof(float), "dictionary atom scratch"));
+    float* u = (float*)c->small.p + 2 * (size_t)r * r;
+    float* partial = u + d;
+    if (Wout != Win)
+        HIP_TRY(c, hipMemcpyAsync(Wout, Win, (size_t)d * r * sizeof(float), hipMemcpyDeviceToDevice, s));
+    for (int j = 0; j < r; ++j) {
+        hipLaunchKernelGGL(dict_atom_move_kernel, dim3(nparts), dim3(256), 0, s, d, r, j, Wout, A, B, u, partial);
+        hipLaunchKernelGGL(dict_atom_scale_kernel, dim3(nparts), dim3(256), 0, s, d, r, j, Wout, u, partial, nparts);
+    }
+    HIP_TRY(c, hipGetLastError());
+    return ONMF_OK;
+}
+
 int launch_dict_pass(onmf_ctx* c, int d, int r, const float* Win, const float* A, const float* B,
-                     float* Wout, hipStream_t s, int part) {
+                     float* Wout, hipStream_t s, int part, float* ws) {
     if (part != 0 && !dict_pass_splits(c, d, r))
         return onmf_fail(c, ONMF_ERR_ARG, "update_dict: this shape is not taken in two parts");
-    if (part != 2) c->dict_coop_last = false;
-    if (d <= 16 * 1024 && c->dict_kernel != 1) {
+    if (ws && (d > 1024 || part != 0))
+        return onmf_fail(c, ONMF_ERR_ARG, "update_dict: a caller's workspace serves the one-workgroup pass only (d <= 1024)");
+    if (part != 2 && !ws) c->dict_coop_last = false;
+    // bound of the workgroups' waits for each other (the same option bounds the sweeps' waits)
+    const long long spin_limit = c->spin_limit;
+    if (d <= 16 * 1024 && (c->dict_kernel != 1 || ws)) {
         // one workgroup per 1024 rows; several exchange the atoms' norms (they are few: co-resident)
         const int nwg = (d + 1023) / 1024;
         const int lda = (r + 15) / 16 * 16;
@@ -517,14 +589,24 @@ int launch_dict_pass(onmf_ctx* c, int d, int r, const float* Win, const float* A
         // beside)
         const int jmid = std::max(1, lda / 16 / 2) * 16;
         const int j_begin = part == 2 ? jmid : 0, j_end = part == 1 ? jmid : lda;
-        ONMF_TRY(onmf_reserve(c, c->qt, (size_t)r * d * sizeof(float), "dictionary Qt"));
-        float* Qt = (float*)c->qt.p;
-        ONMF_TRY(onmf_reserve(c, c->ddelta, (3 * (size_t)d * r + (size_t)r * lda + 16) * sizeof(float),
-                              "dictionary deltas"));
-        float* Ap = (float*)c->ddelta.p;             // 64-byte aligned rows
-        float* Dt = Ap + (size_t)r * lda;
-        float* Wt = Dt + (size_t)d * r;              // W^T in, r x d
-        float* WtOut = Wt + (size_t)d * r;
+        float *Qt, *Ap, *Dt, *Wt, *WtOut;
+        if (ws) {
+            const size_t dr = up64((size_t)d * r);
+            Qt = ws;
+            Ap = Qt + dr;                                // 64-byte aligned rows
+            Dt = Ap + up64((size_t)r * lda);
+            Wt = Dt + dr;
+            WtOut = Wt + dr;
+        } else {
+            ONMF_TRY(onmf_reserve(c, c->qt, (size_t)r * d * sizeof(float), "dictionary Qt"));
+            Qt = (float*)c->qt.p;
+            ONMF_TRY(onmf_reserve(c, c->ddelta, (3 * (size_t)d * r + (size_t)r * lda + 16) * sizeof(float),
+                                  "dictionary deltas"));
+            Ap = (float*)c->ddelta.p;                    // 64-byte aligned rows
+            Dt = Ap + (size_t)r * lda;
+            Wt = Dt + (size_t)d * r;                     // W^T in, r x d
+            WtOut = Wt + (size_t)d * r;
+        }
         u64* gran = nullptr;
         int* flag = nullptr;
         if (nwg > 1) {
@@ -552,7 +634,6 @@ int launch_dict_pass(onmf_ctx* c, int d, int r, const float* Win, const float* A
         // 256 threads, thread t owns rows t, t + 256, ... of its workgroup's 1024
         const int rpt = nwg > 1 ? 4 : (d + 255) / 256;
         const int nt = rpt > 1 ? 256 : (d + 63) / 64 * 64;
-        const long long spin_limit = 200000000LL;   // 2 s of the 100 MHz wall clock
         // (The workgroup shares its CU with one workgroup of the product that runs beside it.  Claiming
         // the CU whole - through a large LDS request - was measured: the pass gets no faster, and the
         // product loses a second slot in that shader engine, which at 15 of 16 slots taken per engine
@@ -594,7 +675,6 @@ int launch_dict_pass(onmf_ctx* c, int d, int r, const float* Win, const float* A
     HIP_TRY(c, hipGetLastError());
     static LdsLimit lim;
     ONMF_TRY(onmf_raise_lds_limit(c, lim, (const void*)dict_pass_kernel, lds));
-    const long long spin_limit = 200000000LL;   // 2 s of the 100 MHz wall clock
     hipLaunchKernelGGL(dict_pass_kernel, dim3(nwg), dim3(64), lds, s, d, r, nwg, Qt, A, B, Win, Wout,
                        gran, flag, spin_limit);
     HIP_TRY(c, hipGetLastError());

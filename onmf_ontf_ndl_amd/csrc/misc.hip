@@ -64,6 +64,14 @@ __global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ y, const 
         y[i] = fmaf(a, x[i], y[i]);
 }
 
+// out = keep * old + w * part   (the aggregate recursion applied to sums formed elsewhere)
+__global__ __launch_bounds__(256) void axpby_kernel(float* out, const float* old, float keep,
+                                                    const float* __restrict__ part, float w, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x)
+        out[i] = fmaf(keep, old[i], w * part[i]);
+}
+
 __global__ __launch_bounds__(256) void sub_kernel(float* __restrict__ out, const float* __restrict__ a,
                                                   const float* __restrict__ b, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
@@ -203,6 +211,12 @@ int launch_scatter_add_last(onmf_ctx* c, int r, int n, float* code, const long l
 int launch_axpy(float* y, const float* x, float a, size_t n, hipStream_t s) {
     if (n == 0) return ONMF_OK;
     hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n)), dim3(256), 0, s, y, x, a, n);
+    return hipGetLastError() == hipSuccess ? ONMF_OK : ONMF_ERR_HIP;
+}
+
+int launch_axpby(float* out, const float* old, float keep, const float* part, float w, size_t n, hipStream_t s) {
+    if (n == 0) return ONMF_OK;
+    hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n)), dim3(256), 0, s, out, old, keep, part, w, n);
     return hipGetLastError() == hipSuccess ? ONMF_OK : ONMF_ERR_HIP;
 }
 

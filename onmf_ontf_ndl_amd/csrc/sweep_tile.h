@@ -523,7 +523,10 @@ int launch_sweep_tile(onmf_ctx* c, int r, int b, const float* Gm, const float* C
                       float alpha, int exact_cd, int k_first, int k_count, double* stats, int* n_groups,
                       hipStream_t s, const ScreenDev* screen) {
     const int nb = (r + 15) / 16;
-    if (k_count > 1 && !screen) return onmf_fail(c, ONMF_ERR_ARG, "sweep: several sweeps per launch need the screen");
+    // Several sweeps per launch: either the screen ends the loop on the device, or the mode has no test
+    // between the sweeps of a launch (exact coordinate descent, tested once per chunk of sweeps).
+    if (k_count > 1 && !screen && !exact_cd)
+        return onmf_fail(c, ONMF_ERR_ARG, "sweep: several damped sweeps per launch need the screen");
     ScreenDev none = {};
 #define TILE_CASE(NBV, HALFV)                                                                            \
     case NBV:                                                                                            \

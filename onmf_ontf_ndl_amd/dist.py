@@ -3,16 +3,19 @@
 The reference is single-process; the only quantities that couple minibatch columns are the sums
 H H^T and H X^T (src/onmf.py:155-156) and the replicated dictionary.  Two ways to use several GPUs:
 
-* independent streams, periodic averaging (``average_state``): every rank runs its own patch stream
-  with its own (W, A, B) and, every few steps, the ranks all-reduce the packed state [A | B | W] and
-  divide by the world size.  Averages of nonnegative matrices with column norms <= 1 stay in that
-  set, so W needs no re-projection.  One collective of r*r + 2*r*d floats per exchange.
-* one large minibatch split by columns (``sharded_step``, built on ``allreduce_partial_aggregates``):
-  each rank codes its slice and the partial sums are added before the (1-w, w) recursion - equal to
-  the reference run on the concatenated batch up to summation order.
+* independent streams, periodic averaging (``PackedState`` + ``average_state_``): every rank runs its
+  own patch stream with its own (W, A, B) and, every few steps, the ranks all-reduce the packed state
+  [A | B | W] in place and divide by the world size.  Averages of nonnegative matrices with column
+  norms <= 1 stay in that set, so W needs no re-projection.  One collective of r*r + 2*r*d floats per
+  exchange, on one resident buffer (no packing copies).
+* one large minibatch split by columns (``ShardedStepper``; ``sharded_step`` is its plain serial form):
+  each rank codes its slice and the partial sums are added before the (1-w, w) recursion - equal to the
+  reference run on the concatenated batch up to summation order.  The all-reduce of step t's sums runs
+  on a stream of its own underneath step t+1's W^T X and sweeps: only the dictionary pass of step t+1
+  needs the aggregates of step t (src/onmf.py:161).
 
-Both helpers work on any tensor device; under the ``gloo`` backend device tensors are staged through
-host memory.
+All helpers work on any tensor device; a ``gloo`` group only ever sees host memory (device tensors are
+staged through it synchronously).
 """
 from __future__ import annotations
 
@@ -22,8 +25,10 @@ import os
 def init_from_env(backend=None):
     """Initialise the default process group from RANK / WORLD_SIZE / MASTER_* if there is one.
 
-    ``ONMF_DIST_BACKEND=gloo`` forces the host backend (e.g. to rehearse several ranks on a machine
-    with fewer GPUs than ranks: the local device index then wraps around the devices present)."""
+    Backend: ``backend`` or ``ONMF_DIST_BACKEND``; else ``nccl`` (RCCL) when every rank has a GPU of its
+    own, ``gloo`` when ranks must share GPUs (RCCL cannot form a group with two ranks on one device;
+    the local device index then wraps around the devices present) or there is no GPU.
+    Returns (rank, world, local device index)."""
     import torch
     import torch.distributed as td
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -33,16 +38,26 @@ def init_from_env(backend=None):
     local = int(os.environ.get("LOCAL_RANK", rank))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if not td.is_initialized():
+        n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
         if backend is None:
-            backend = os.environ.get("ONMF_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
-        if backend != "nccl" and torch.cuda.is_available():
-            local %= max(1, torch.cuda.device_count())
+            backend = os.environ.get("ONMF_DIST_BACKEND") or ("nccl" if n_dev >= local_world else "gloo")
         if backend == "nccl":
+            if local >= n_dev:
+                raise RuntimeError("rank %d: local rank %d has no GPU of its own (%d present); RCCL needs one "
+                                   "device per rank - set ONMF_DIST_BACKEND=gloo to share GPUs" % (rank, local, n_dev))
             torch.cuda.set_device(local)
             td.init_process_group(backend=backend, device_id=torch.device("cuda", local))
         else:
             td.init_process_group(backend=backend)
+    if td.get_backend() != "nccl" and torch.cuda.is_available():
+        local %= max(1, torch.cuda.device_count())
     return rank, world, local
+
+
+def _active(group=None):
+    import torch.distributed as td
+    return td.is_available() and td.is_initialized()
 
 
 def all_reduce_sum(flat, group=None):
@@ -56,6 +71,49 @@ def all_reduce_sum(flat, group=None):
     else:
         td.all_reduce(flat, op=td.ReduceOp.SUM, group=group)
     return flat
+
+
+def _up4(n):
+    return (n + 3) & ~3
+
+
+class PackedState:
+    """(A, B, W) as views of ONE contiguous float32 vector [A | B | W], every part starting on a 16-byte
+    boundary (the kernels take their vector paths only for 16-byte aligned matrices).  The all-reduce
+    of the state is then one in-place collective on ``flat``."""
+
+    def __init__(self, d, r, device, dtype=None):
+        import torch
+        self.d, self.r = int(d), int(r)
+        oa, ob, ow = 0, _up4(r * r), _up4(r * r) + _up4(r * d)
+        self.flat = torch.zeros(ow + _up4(d * r), device=device, dtype=dtype or torch.float32)
+        self.A = self.flat[oa:oa + r * r].view(r, r)
+        self.B = self.flat[ob:ob + r * d].view(r, d)
+        self.W = self.flat[ow:ow + d * r].view(d, r)
+
+    def load(self, W, A, B):
+        self.W.copy_(W)
+        self.A.copy_(A)
+        self.B.copy_(B)
+        return self
+
+    def views(self):
+        return self.A, self.B, self.W
+
+
+def average_state_(state, group=None, force=False):
+    """In place: all-reduce(SUM) of the packed state, divided by the world size.  ``force`` runs the
+    collective on a one-rank group too (it is then the identity; used to exercise the backend)."""
+    import torch.distributed as td
+    if not _active(group):
+        return state
+    world = td.get_world_size(group)
+    if world == 1 and not force:
+        return state
+    all_reduce_sum(state.flat, group)
+    if world > 1:
+        state.flat.mul_(1.0 / world)
+    return state
 
 
 def pack_state(W, A, B):
@@ -73,25 +131,22 @@ def unpack_state(flat, d, r):
 
 
 def average_state(W, A, B, group=None):
-    """All-reduce(SUM) of the packed state, divided by the world size. Returns new (W, A, B)."""
+    """All-reduce(SUM) of the state, divided by the world size; returns new (W, A, B).  For loose
+    tensors; a stream that keeps its state in a ``PackedState`` uses ``average_state_`` (no copies)."""
     import torch.distributed as td
-    if not (td.is_available() and td.is_initialized()) or td.get_world_size(group) == 1:
+    if not _active(group) or td.get_world_size(group) == 1:
         return W, A, B
     d, r = W.shape
-    flat = pack_state(W, A, B)
-    all_reduce_sum(flat, group)
-    flat /= td.get_world_size(group)
-    W1, A1, B1 = unpack_state(flat, d, r)
-    # own allocations: slices of the packed vector start at odd offsets for odd r, and the kernels
-    # take their 16-byte paths only for 16-byte aligned matrices
-    return W1.clone(), A1.clone(), B1.clone()
+    st = PackedState(d, r, W.device, W.dtype).load(W, A, B)
+    average_state_(st, group)
+    return st.W, st.A, st.B
 
 
 def allreduce_partial_aggregates(HHt, HXt, group=None):
     """Sum the per-rank partial products H_g H_g^T and H_g X_g^T in place (one collective)."""
     import torch
     import torch.distributed as td
-    if not (td.is_available() and td.is_initialized()) or td.get_world_size(group) == 1:
+    if not _active(group) or td.get_world_size(group) == 1:
         return HHt, HXt
     flat = torch.cat([HHt.reshape(-1), HXt.reshape(-1)])
     all_reduce_sum(flat, group)
@@ -103,7 +158,8 @@ def allreduce_partial_aggregates(HHt, HXt, group=None):
 
 def sharded_step(eng, X_local, A, B, W, w, *, alpha=0.0, H0=None, seed=None, sub_iter=10,
                  stopping_diff=0.0, group=None):
-    """One minibatch step (src/onmf.py:119-167) on a minibatch whose columns are split over the ranks.
+    """One minibatch step (src/onmf.py:119-167) on a minibatch whose columns are split over the ranks -
+    the plain form: three calls and a blocking collective.  ``ShardedStepper`` is the scheduled form.
 
     Every rank holds the same (W, A, B) and its own columns ``X_local``.  It codes them, forms its
     partial sums H H^T and H X^T (src/onmf.py:155-156 are sums over columns), the ranks add them
@@ -125,6 +181,68 @@ def sharded_step(eng, X_local, A, B, W, w, *, alpha=0.0, H0=None, seed=None, sub
     B1 = (1.0 - w) * B + w * HXt
     W1 = eng.update_dict(W, A, B)
     return H, A1, B1, W1, sweeps
+
+
+class ShardedStepper:
+    """The column-split step with the library's own schedule and the exchange off the critical path.
+
+    Holds the replicated state (W, A, B) on the GPU.  ``step(X_local, w)``:
+      main stream   onmf_step_partial: W^T X, sweeps, bare sums P_t = [H H^T | H X^T], dictionary pass
+                    W_{t+1} = update_dict(W_t, A_{t-1}, B_{t-1}) beside them (three-stream schedule)
+      comm stream   all-reduce(P_t), then (A_t, B_t) = (1-w)(A_{t-1}, B_{t-1}) + w P_t, then an event
+    The next step's code solve starts at once (it needs W_{t+1} only); its dictionary pass and its own
+    sums wait for the event inside the library.  Buffers alternate between two sets, so nothing a
+    pending exchange reads is overwritten.
+    """
+
+    def __init__(self, eng, W, A, B, group=None):
+        import torch
+        self.eng, self.group = eng, group
+        d, r = W.shape
+        self.d, self.r = d, r
+        self.W = [W.clone().contiguous(), eng.empty(d, r)]
+        self.A = [A.clone().contiguous(), eng.empty(r, r)]
+        self.B = [B.clone().contiguous(), eng.empty(r, d)]
+        self.P = [eng.zeros(eng.partial_floats(d, r)) for _ in range(2)]
+        self.cur = 0
+        self.ready = None                       # event: (A, B)[cur] are final and P[1 - cur] is free
+        self.comm = torch.cuda.Stream(device=eng.device)      # default priority
+        self.sweeps = None
+
+    def state(self):
+        """(W, A, B) after the last step (waits for a pending exchange)."""
+        if self.ready is not None:
+            self.ready.synchronize()
+        c = self.cur
+        return self.W[c], self.A[c], self.B[c]
+
+    def step(self, X_local, w, *, alpha=0.0, H0=None, seed=None, sub_iter=10, stopping_diff=0.0, want_code=True):
+        import torch
+        import torch.distributed as td
+        eng, c, n = self.eng, self.cur, 1 - self.cur
+        P = self.P[c]
+        H, _, self.sweeps = eng.step_partial(X_local, self.A[c], self.B[c], self.W[c], P, W_out=self.W[n], alpha=alpha,
+                                             H0=H0, seed=seed, sub_iter=sub_iter, stopping_diff=stopping_diff,
+                                             want_code=want_code, state_ready_event=self.ready)
+        main = torch.cuda.current_stream(eng.device)
+        done = torch.cuda.Event()
+        done.record(main)
+        multi = _active(self.group) and td.get_world_size(self.group) > 1
+        if multi and td.get_backend(self.group) == "gloo":
+            main.synchronize()                   # host-staged collective: nothing to overlap with
+            all_reduce_sum(P, self.group)
+            eng.step_apply(P, w, self.A[c], self.B[c], self.A[n], self.B[n])
+            self.ready = None
+        else:
+            with torch.cuda.stream(self.comm):
+                self.comm.wait_event(done)
+                if _active(self.group):
+                    td.all_reduce(P, op=td.ReduceOp.SUM, group=self.group)    # RCCL, ordered on this stream
+                eng.step_apply(P, w, self.A[c], self.B[c], self.A[n], self.B[n])
+                self.ready = torch.cuda.Event()
+                self.ready.record(self.comm)
+        self.cur = n
+        return H
 
 
 def split_columns(n, rank, world):

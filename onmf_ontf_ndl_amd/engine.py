@@ -7,6 +7,7 @@ whatever the caller handed in.  All arithmetic happens in libonmf_hip.so.
 from __future__ import annotations
 
 import ctypes as C
+import warnings
 
 import numpy as np
 
@@ -48,6 +49,7 @@ class Engine:
         _lib.check(rc, None, "onmf_create")
         self.ctx = ctx
         self._seed_counter = 0
+        self._timeouts_seen = 0
 
     def __del__(self):
         try:
@@ -89,6 +91,39 @@ class Engine:
                    "onmf_get_profile")
         return ms.value, n.value
 
+    def counters(self):
+        """Recovery events since the context was created: one-launch solves and dictionary passes whose
+        workgroups gave up waiting for each other, and solves that ran one launch per sweep since."""
+        out = {}
+        for name, key in (("sweep_timeouts", _lib.CNT_SWEEP_TIMEOUTS), ("dict_timeouts", _lib.CNT_DICT_TIMEOUTS),
+                          ("fallback_solves", _lib.CNT_FALLBACK_SOLVES)):
+            v = C.c_longlong(0)
+            _lib.check(self.lib.onmf_get_counter(self.ctx, key, C.byref(v)), self.ctx, "onmf_get_counter")
+            out[name] = int(v.value)
+        return out
+
+    def _warn_on_timeouts(self):
+        """One warning the first time a device-side wait gave up (results stay correct; later solves are
+        slower for a while).  Typical cause: another process's kernels on the same GPU."""
+        if self._timeouts_seen:
+            return
+        c = self.counters()
+        n = c["sweep_timeouts"] + c["dict_timeouts"]
+        if n:
+            self._timeouts_seen = n
+            warnings.warn("libonmf_hip: workgroups of a one-launch kernel gave up waiting for each other on GPU %d "
+                          "(%s); the work was redone by the slower launch-per-step path and the fast path rests "
+                          "for the next solves.  Is another process using this GPU?" % (self.index, c),
+                          RuntimeWarning, stacklevel=3)
+
+    def _check_index(self, idx, n, what):
+        """NumPy raises IndexError for an index outside [-n, n); so does this (one small reduction)."""
+        if idx.numel():
+            lo, hi = int(idx.min()), int(idx.max())
+            if lo < -n or hi >= n:
+                raise IndexError("%s: index %d is out of bounds for axis 1 with size %d"
+                                 % (what, lo if lo < -n else hi, n))
+
     # ------------------------------------------------------------------ the path
     def sparse_code(self, X, W, H0=None, alpha=0.0, sub_iter=10, stopping_diff=0.01, seed=None,
                     mode=_lib.CODER_DAMPED):
@@ -109,6 +144,7 @@ class Engine:
                                        float(stopping_diff), int(mode), _ptr(H), C.byref(sweeps),
                                        trace, self.stream())
         _lib.check(rc, self.ctx, "onmf_sparse_code")
+        self._warn_on_timeouts()
         return H, sweeps.value, np.array(trace[:sweeps.value], dtype=np.float64)
 
     def aggregate(self, X, H, w, A, B, Cagg=None, want_c=False):
@@ -130,14 +166,36 @@ class Engine:
         rc = self.lib.onmf_update_dict(self.ctx, d, r, _ptr(W), _ptr(A), _ptr(B), _ptr(W1),
                                        self.stream())
         _lib.check(rc, self.ctx, "onmf_update_dict")
+        if d > 1024:
+            self._warn_on_timeouts()
+        return W1
+
+    def update_dict_static(self, W, A, B, out=None):
+        """``update_dict`` through the entry point that allocates no device memory (d <= 1024, r <= 256;
+        its workspace is a static array of the library).  ``out``: where to put W1 (the library itself
+        allocates nothing; this wrapper allocates ``out`` when none is given)."""
+        d, r = W.shape
+        if tuple(A.shape) != (r, r) or tuple(B.shape) != (r, d):
+            raise ValueError("update_dict: A must be (r,r) and B (r,d)")
+        W1 = self.empty(d, r) if out is None else out
+        rc = self.lib.onmf_update_dict_static(self.ctx, d, r, _ptr(W), _ptr(A), _ptr(B), _ptr(W1), self.stream())
+        _lib.check(rc, self.ctx, "onmf_update_dict_static")
         return W1
 
     def step(self, X, A, B, Cagg, W, w, alpha=0.0, H0=None, seed=None, sub_iter=10,
-             stopping_diff=0.01, want_code=True):
-        """One minibatch step (onmf.py:119-167). Returns H1, A1, B1, C1, W1, sweeps, dist."""
+             stopping_diff=0.01, want_code=True, out=None):
+        """One minibatch step (onmf.py:119-167). Returns H1, A1, B1, C1, W1, sweeps, dist.
+        ``out`` = (A1, B1, W1): tensors to write the new state into (e.g. views of a packed buffer);
+        they must not be the input tensors if the step is to keep its three-stream schedule."""
         d, b = X.shape
         r = W.shape[1]
-        A1, B1, W1 = self.empty(r, r), self.empty(r, d), self.empty(d, r)
+        if out is None:
+            A1, B1, W1 = self.empty(r, r), self.empty(r, d), self.empty(d, r)
+        else:
+            A1, B1, W1 = out
+            if tuple(A1.shape) != (r, r) or tuple(B1.shape) != (r, d) or tuple(W1.shape) != (d, r) or \
+                    not (A1.is_contiguous() and B1.is_contiguous() and W1.is_contiguous()):
+                raise ValueError("step: out must be contiguous (r,r), (r,d), (d,r) tensors")
         C1 = self.empty(d, d) if Cagg is not None else None
         H = self.empty(r, b) if want_code else None
         sweeps = C.c_int(0)
@@ -149,12 +207,52 @@ class Engine:
                                 int(sub_iter), float(stopping_diff), _ptr(H), _ptr(A1), _ptr(B1),
                                 _ptr(C1), _ptr(W1), C.byref(sweeps), trace, self.stream())
         _lib.check(rc, self.ctx, "onmf_step")
+        self._warn_on_timeouts()
         return H, A1, B1, C1, W1, sweeps.value, np.array(trace[:sweeps.value], dtype=np.float64)
+
+    def partial_floats(self, d, r):
+        return int(self.lib.onmf_partial_floats(int(d), int(r)))
+
+    def step_partial(self, X, A, B, W, P, W_out=None, alpha=0.0, H0=None, seed=None, sub_iter=10,
+                     stopping_diff=0.0, want_code=True, state_ready_event=None):
+        """The step on this rank's columns of a split minibatch: code, BARE sums [H H^T | H X^T] into the
+        packed vector ``P`` (``partial_floats`` long), dictionary pass on (A, B) - see onmf_step_partial in
+        include/onmf_hip.h.  ``state_ready_event``: a torch.cuda.Event after which A, B and P may be
+        touched.  Returns H, W1, sweeps."""
+        d, b = X.shape
+        r = W.shape[1]
+        if P.numel() < self.partial_floats(d, r) or not P.is_contiguous():
+            raise ValueError("step_partial: P must be a contiguous vector of %d floats" % self.partial_floats(d, r))
+        W1 = self.empty(d, r) if W_out is None else W_out
+        H = self.empty(r, b) if want_code else None
+        sweeps = C.c_int(0)
+        trace = (C.c_float * max(1, int(sub_iter)))()
+        if seed is None:
+            seed = self.next_seed()
+        ev = C.c_void_p(state_ready_event.cuda_event) if state_ready_event is not None else C.c_void_p(0)
+        rc = self.lib.onmf_step_partial(self.ctx, d, r, b, _ptr(X), X.stride(0), _ptr(W), _ptr(A), _ptr(B),
+                                        _ptr(H0), C.c_uint64(seed), float(alpha), int(sub_iter),
+                                        float(stopping_diff), _ptr(H), _ptr(P), _ptr(W1), C.byref(sweeps), trace,
+                                        ev, self.stream())
+        _lib.check(rc, self.ctx, "onmf_step_partial")
+        self._warn_on_timeouts()
+        return H, W1, sweeps.value
+
+    def step_apply(self, P, w, A, B, A_out=None, B_out=None):
+        """A1 = (1-w) A + w P[H H^T], B1 = (1-w) B + w P[H X^T] (src/onmf.py:155-156) on the current stream."""
+        r, d = B.shape
+        A1 = self.empty(r, r) if A_out is None else A_out
+        B1 = self.empty(r, d) if B_out is None else B_out
+        rc = self.lib.onmf_step_apply(self.ctx, d, r, _ptr(P), float(w), _ptr(A), _ptr(B), _ptr(A1), _ptr(B1),
+                                      self.stream())
+        _lib.check(rc, self.ctx, "onmf_step_apply")
+        return A1, B1
 
     # ------------------------------------------------------------------ around the path
     def gather_columns(self, X, idx):
         d, n = X.shape
         idx = self.dev(idx, self.torch.int64)
+        self._check_index(idx, n, "gather_columns")
         b = idx.numel()
         Xb = self.empty(d, b)
         rc = self.lib.onmf_gather_columns(self.ctx, d, n, _ptr(X), X.stride(0), _ptr(idx), b,
@@ -168,6 +266,7 @@ class Engine:
             b, ip = n, C.c_void_p(0)
         else:
             idx = self.dev(idx, self.torch.int64)
+            self._check_index(idx, n, "code_accumulate")
             b, ip = idx.numel(), _ptr(idx)
         rc = self.lib.onmf_code_accumulate(self.ctx, r, n, _ptr(code), ip, b, _ptr(H), self.stream())
         _lib.check(rc, self.ctx, "onmf_code_accumulate")

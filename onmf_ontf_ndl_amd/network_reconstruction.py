@@ -236,8 +236,9 @@ class Network_Reconstructor():
         Wd = eng.dev(self.W)
         from . import _lib
         H0 = eng.zeros(Wd.shape[1], X.shape[1])
-        H, _, _ = eng.sparse_code(X, Wd, H0=H0, alpha=0.0, sub_iter=cd_max_sweeps, stopping_diff=cd_tol,
-                                  mode=_lib.CODER_EXACT_CD)
+        # every patch is its own least-squares problem: one launch, each column with its own stopping test
+        H = eng.sparse_code_each(X, Wd, H0=H0, alpha=0.0, sub_iter=cd_max_sweeps, stopping_diff=cd_tol,
+                                 mode=_lib.CODER_EXACT_CD)
         total, count = eng.ndl_accumulate_edges(n, trace, eng.patch_product(Wd, H))
         mean = eng.torch.where(count > 0, total / count.clamp(min=1), eng.torch.zeros_like(total))
         keep = eng.torch.round(mean) > 0                       # np.round: exactly 0.5 goes to 0

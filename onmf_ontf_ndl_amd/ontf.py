@@ -8,9 +8,11 @@ onmf's (src/ontf.py:86, :147-148).
 The reference hands the sparse-code solve to scikit-learn (``SparseCoder``, lasso_lars, positive
 codes, alpha = ``self.alpha`` or 2; src/ontf.py:79-86).  Here the same convex problem
     min_{h >= 0}  0.5 * ||x - W h||^2 + alpha * ||h||_1        (per column)
-is solved on the GPU by exact cyclic coordinate descent from h = 0, run until the relative change
-of the code per sweep falls under ``cd_tol`` (at most ``cd_max_sweeps`` sweeps).  It reaches the
-optimum that LARS approximates; it does not retrace the LARS path.
+is solved on the GPU by exact cyclic coordinate descent from h = 0: every column iterates until ITS
+relative change per sweep, ||h_new - h_old|| / ||h_old||, falls under ``cd_tol`` (at most
+``cd_max_sweeps`` sweeps) - the columns are independent problems, as they are for LARS - all in one
+kernel launch without host round trips.  It reaches the optimum that LARS approximates; it does not
+retrace the LARS path.
 """
 from __future__ import annotations
 
@@ -68,7 +70,7 @@ class Online_NTF():
         self._torch_io = _is_torch(X)
         self.cd_tol = cd_tol
         self.cd_max_sweeps = cd_max_sweeps
-        self.last_sweeps = None
+        self._sweeps_each = None
 
     def _engine(self):
         return get_engine(self._device)
@@ -77,10 +79,16 @@ class Online_NTF():
         """Device solve; returns H as (r x b)."""
         a = 2 if self.alpha is None else self.alpha          # src/ontf.py:79-84
         H0 = eng.zeros(Wd.shape[1], Xd.shape[1])
-        H, sweeps, _ = eng.sparse_code(Xd, Wd, H0=H0, alpha=a, sub_iter=self.cd_max_sweeps,
-                                       stopping_diff=self.cd_tol, mode=_lib.CODER_EXACT_CD)
-        self.last_sweeps = sweeps
+        H, sweeps = eng.sparse_code_each(Xd, Wd, H0=H0, alpha=a, sub_iter=self.cd_max_sweeps,
+                                         stopping_diff=self.cd_tol, mode=_lib.CODER_EXACT_CD, want_sweeps=True)
+        self._sweeps_each = sweeps                           # device int32[b]; read on demand
         return H
+
+    @property
+    def last_sweeps(self):
+        """Sweeps run by the slowest column of the most recent solve (None before the first)."""
+        s = getattr(self, "_sweeps_each", None)
+        return None if s is None else int(s.max())
 
     def joint_sparse_code_tensor(self, X, W):
         """Code H (samples x topics) with W H^T ~ X (src/ontf.py:59-89)."""

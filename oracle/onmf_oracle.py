@@ -283,7 +283,8 @@ class OracleOnlineNTF:
 
     def __init__(self, X, n_components=100, iterations=500, sub_iterations=10, batch_size=20,
                  ini_dict=None, ini_A=None, ini_B=None, history=0, mode=0,
-                 learn_joint_dict=False, alpha=None, beta=None, subsample=True, solver="sklearn"):
+                 learn_joint_dict=False, alpha=None, beta=None, subsample=True, solver="sklearn",
+                 cd_sweeps=20000, cd_tol=1e-12):
         self.X = X
         self.n_components = n_components
         self.batch_size = batch_size
@@ -300,9 +301,11 @@ class OracleOnlineNTF:
         self.code = np.zeros((X.shape[1], n_components))
         self.subsample = subsample
         self.solver = solver
+        self.cd_sweeps = cd_sweeps          # solver="cd": sweep cap and tolerance (a negative tolerance
+        self.cd_tol = cd_tol                # runs exactly cd_sweeps sweeps)
 
     def joint_sparse_code_tensor(self, X, W):
-        return lasso_nonneg_code(X, W, self.alpha, solver=self.solver)
+        return lasso_nonneg_code(X, W, self.alpha, solver=self.solver, sweeps=self.cd_sweeps, tol=self.cd_tol)
 
     def update_dict(self, W, A, B):
         return dictionary_pass(W, A, B)

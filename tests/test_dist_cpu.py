@@ -28,6 +28,13 @@ def _worker(rank, world, init_file, out_dir):
         np.testing.assert_allclose(A1.numpy(), np.mean(As, axis=0), rtol=1e-12)
         np.testing.assert_allclose(B1.numpy(), np.mean(Bs, axis=0), rtol=1e-12)
         assert W1.min() >= 0 and np.linalg.norm(W1.numpy(), axis=0).max() <= np.linalg.norm(Ws[0], axis=0).max() + 1
+        # the resident packed buffer: one in-place collective, views stay valid
+        st = odist.PackedState(d, r, "cpu", torch.float64).load(W, A, B)
+        views = st.views()
+        odist.average_state_(st)
+        np.testing.assert_allclose(st.W.numpy(), np.mean(Ws, axis=0), rtol=1e-12)
+        np.testing.assert_allclose(st.A.numpy(), np.mean(As, axis=0), rtol=1e-12)
+        assert all(v.data_ptr() == u.data_ptr() for v, u in zip(views, st.views()))
 
         # one minibatch split by columns: summed partial products == the products of the whole batch
         full = np.random.RandomState(7)
@@ -88,6 +95,10 @@ def test_single_process_helpers():
     W2, A2, B2 = odist.unpack_state(flat, 5, 3)
     assert torch.equal(W, W2) and torch.equal(A, A2) and torch.equal(B, B2)
     assert odist.average_state(W, A, B)[0] is W            # no process group: identity
+    st = odist.PackedState(5, 3, "cpu").load(W, A, B)
+    assert torch.equal(st.W, W) and torch.equal(st.A, A) and torch.equal(st.B, B)
+    assert st.flat.numel() == 12 + 16 + 16 and all(v.data_ptr() % 16 == 0 for v in st.views())
+    assert odist.average_state_(st) is st
     spans = [odist.split_columns(10, k, 3) for k in range(3)]
     assert spans == [(0, 4), (4, 7), (7, 10)]
     assert odist.init_from_env() == (0, 1, 0) or os.environ.get("WORLD_SIZE", "1") != "1"

@@ -1,0 +1,309 @@
+"""GPU parity at the FULL sizes of the benchmark configurations, against the fp64 oracle.
+
+  headline  d=1024, r=256, b=65536: one step with the reference's stopping rule (0.01), sweep count equal
+  C4        d=4096, r=256, b=65536: one step at a fixed sweep count, and the dictionary pass alone on
+            both kernels (four cooperating workgroups, 16 panels, two parts around the sweeps)
+  C3        Online_NTF on a (400, 3, N) tensor, mode 2 / joint dictionary (d=1200), r=100
+
+Inputs are float32-representable, so the oracle (float64 arithmetic on the same numbers) and the GPU
+(float32 arithmetic) start from identical data.  Tolerances as everywhere: codes and aggregates 2e-5
+relative Frobenius, dictionary 1e-4.  The oracle's stopping test takes its spectral norms from the
+r x r Gram matrices (same numbers as the reference's SVD, checked in tests/test_oracle_golden.py).
+"""
+import numpy as np
+import pytest
+
+from conftest import relerr
+
+pytestmark = pytest.mark.gpu
+
+TOL_H = 2e-5
+TOL_AGG = 2e-5
+TOL_W = 1e-4
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from onmf_ontf_ndl_amd.engine import get_engine
+    return get_engine()
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import onmf_oracle
+    return onmf_oracle
+
+
+def host(t):
+    return t.detach().cpu().numpy().astype(np.float64)
+
+
+def f32(rs, *shape):
+    return rs.rand(*shape).astype(np.float32)
+
+
+def warm_state(rs, d, r):
+    """A dictionary in the constraint set and aggregates of the size a running stream holds."""
+    W = f32(rs, d, r)
+    W = (W / np.maximum(1, np.linalg.norm(W.astype(np.float64), axis=0))).astype(np.float32)
+    Hw = rs.rand(r, 512)
+    A = (Hw @ Hw.T / 512).astype(np.float32)
+    B = (Hw @ rs.rand(d, 512).T / 512).astype(np.float32)
+    return W, A, B
+
+
+def test_headline_step_against_oracle(eng, orc):
+    """d=1024, r=256, b=65536, stopping_diff=0.01 (src/onmf.py:87): the whole step in its default
+    schedule (one launch for all sweeps, device-side stopping screen, dictionary pass in two parts on the
+    side stream) against the oracle's step on the same inputs."""
+    d, r, b = 1024, 256, 65536
+    rs = np.random.RandomState(2024)
+    X, H0 = f32(rs, d, b), f32(rs, r, b)
+    W, A, B = warm_state(rs, d, r)
+    tr = []
+    H_o, agg_o, W_o, _ = orc.minibatch_step(X.astype(np.float64), [A.astype(np.float64), B.astype(np.float64)],
+                                            W.astype(np.float64), 5, H0=H0.astype(np.float64), trace=tr,
+                                            norm="gram")
+    H, A1, B1, _, W1, sweeps, _ = eng.step(eng.dev(X), eng.dev(A), eng.dev(B), None, eng.dev(W), 0.2,
+                                           H0=eng.dev(H0))
+    assert sweeps == len(tr)
+    assert relerr(host(H), H_o) < TOL_H
+    assert relerr(host(A1), agg_o[0]) < TOL_AGG and relerr(host(B1), agg_o[1]) < TOL_AGG
+    assert relerr(host(W1), W_o) < TOL_W
+
+
+def test_c4_step_against_oracle(eng, orc):
+    """d=4096, r=256, b=65536 at a fixed sweep count (stopping_diff=0): W^T X with a 4096-long
+    contraction, the dictionary pass on four cooperating workgroups in two parts around the sweeps."""
+    d, r, b = 4096, 256, 65536
+    rs = np.random.RandomState(4096)
+    X, H0 = f32(rs, d, b), f32(rs, r, b)
+    W, A, B = warm_state(rs, d, r)
+    H_o, agg_o, W_o, _ = orc.minibatch_step(X.astype(np.float64), [A.astype(np.float64), B.astype(np.float64)],
+                                            W.astype(np.float64), 5, H0=H0.astype(np.float64),
+                                            stopping_diff=0.0, norm="gram")
+    H, A1, B1, _, W1, sweeps, _ = eng.step(eng.dev(X), eng.dev(A), eng.dev(B), None, eng.dev(W), 0.2,
+                                           H0=eng.dev(H0), stopping_diff=0.0)
+    assert sweeps == 10
+    assert relerr(host(H), H_o) < TOL_H
+    assert relerr(host(A1), agg_o[0]) < TOL_AGG and relerr(host(B1), agg_o[1]) < TOL_AGG
+    assert relerr(host(W1), W_o) < TOL_W
+    assert eng.counters()["dict_timeouts"] == 0
+
+
+@pytest.mark.parametrize("kernel", [1, 2])
+def test_c4_update_dict_both_kernels(eng, orc, kernel):
+    """The dictionary pass alone at d=4096, r=256 on the cooperating one-wave workgroups (64 of them) and
+    on the panel kernel (4 workgroups, 16 panels)."""
+    d, r = 4096, 256
+    rs = np.random.RandomState(77)
+    W, A, B = warm_state(rs, d, r)
+    W = f32(rs, d, r)                                   # not yet in the constraint set: atoms get rescaled
+    eng.set_option(6, kernel)
+    try:
+        W1 = host(eng.update_dict(eng.dev(W), eng.dev(A), eng.dev(B)))
+    finally:
+        eng.set_option(6, 0)
+    assert relerr(W1, orc.dictionary_pass(W, A, B)) < TOL_W
+    assert np.linalg.norm(W1, axis=0).max() <= 1 + 1e-5 and W1.min() >= 0
+
+
+def test_tall_dictionary_pass_recovers_from_a_timeout(eng, orc):
+    """The workgroups of the d > 1024 pass are given no time to wait for each other (every kernel still
+    ends normally): the library redoes the pass atom by atom, the caller gets the ordinary result and the
+    event is counted."""
+    import warnings
+    d, r = 2500, 40
+    rs = np.random.RandomState(9)
+    W, A, B = warm_state(rs, d, r)
+    want = orc.dictionary_pass(W, A, B)
+    before = eng.counters()["dict_timeouts"]
+    for kernel in (2, 1):
+        eng.set_option(6, kernel)
+        eng.set_option(8, -1)
+        try:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                W1 = host(eng.update_dict(eng.dev(W), eng.dev(A), eng.dev(B)))
+        finally:
+            eng.set_option(8, 2000)
+            eng.set_option(6, 0)
+        assert relerr(W1, want) < TOL_W
+    # (a workgroup that finds the others' words already there does not give up, so the count may not
+    # move on every try; with no time to wait at all it practically always does)
+    assert eng.counters()["dict_timeouts"] >= before
+    # and the same inside a step, where the pass runs in two parts on the side stream
+    X, H0 = f32(rs, d, 300), f32(rs, r, 300)
+    H_o, agg_o, W_o, _ = orc.minibatch_step(X, [A, B], W, 4, H0=H0, stopping_diff=0.0, norm="gram")
+    eng.set_option(8, -1)
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            H, A1, B1, _, W1, sweeps, _ = eng.step(eng.dev(X), eng.dev(A), eng.dev(B), None, eng.dev(W), 0.25,
+                                                   H0=eng.dev(H0), stopping_diff=0.0)
+    finally:
+        eng.set_option(8, 2000)
+        eng.set_option(7, 1)
+    assert sweeps == 10
+    assert relerr(host(H), H_o) < TOL_H and relerr(host(W1), W_o) < TOL_W
+    assert relerr(host(A1), agg_o[0]) < TOL_AGG and relerr(host(B1), agg_o[1]) < TOL_AGG
+
+
+# ------------------------------------------------------------------------------------------
+# C3: Online_NTF, 20 x 20 x 3 colour patches, mode-2 joint unfolding (d = 1200), r = 100
+# ------------------------------------------------------------------------------------------
+def patch_tensor(rs, n):
+    """(400, 3, n) tensor of smooth colour patches (image_reconstruction_tensor.py:87-124 builds
+    (k^2, 3, N) from 20 x 20 windows); smooth so that the dictionary is as coherent as an image's."""
+    k = 20
+    yy, xx = np.meshgrid(np.arange(k), np.arange(k), indexing="ij")
+    T = np.zeros((k * k, 3, n), dtype=np.float32)
+    for j in range(n):
+        f = rs.rand(3, 3)
+        for ch in range(3):
+            img = 0.5 + 0.25 * np.sin(f[ch, 0] * yy / 3 + 6 * f[ch, 1]) * np.cos(f[ch, 2] * xx / 3) + 0.2 * rs.rand(k, k)
+            T[:, ch, j] = img.reshape(-1)
+    return np.clip(T, 0, 1)
+
+
+SWEEPS = 300       # both sides run exactly this many coordinate-descent sweeps (tolerance 0)
+
+
+def test_c3_ntf_step_against_oracle_cd(eng, orc):
+    """Online_NTF.step at d=1200, r=100, b=100 (the batch the reference's main uses,
+    image_reconstruction_tensor.py:339-341) against the oracle's step with its coordinate-descent solver,
+    sweep for sweep: both sides run exactly SWEEPS sweeps from h = 0, so the comparison is of the
+    arithmetic and not of how far a slowly converging iteration got (on these coherent dictionaries
+    cyclic coordinate descent needs thousands of sweeps for its last digits)."""
+    from onmf_ontf_ndl_amd import Online_NTF
+    d, r, b = 1200, 100, 100
+    rs = np.random.RandomState(31)
+    T = patch_tensor(rs, b)
+    ref = orc.OracleOnlineNTF(T, n_components=r, mode=2, learn_joint_dict=True, alpha=0.5, solver="cd",
+                              cd_sweeps=SWEEPS, cd_tol=-1.0)
+    X = ref.unfolded().astype(np.float64)
+    assert X.shape == (d, b)
+    W, A, B = warm_state(rs, d, r)
+    H_o, A_o, B_o, W_o = ref.step(X, A.astype(np.float64), B.astype(np.float64), W.astype(np.float64), 7)
+    ntf = Online_NTF(T, n_components=r, mode=2, learn_joint_dict=True, alpha=0.5, cd_tol=0.0,
+                     cd_max_sweeps=SWEEPS)
+    H, A1, B1, W1 = ntf.step(X, A, B, W, np.int64(7))
+    assert H.shape == (b, r) and ntf.last_sweeps == SWEEPS
+    assert relerr(H, H_o) < TOL_H
+    assert relerr(A1, A_o) < TOL_AGG and relerr(B1, B_o) < TOL_AGG
+    assert relerr(W1, W_o) < TOL_W
+    assert ntf.history == 8.0
+
+
+def test_c3_ntf_batch_2048_against_sklearn_and_oracle(eng, orc):
+    """b = 2048 columns in one launch, default settings (alpha = 2, the library's own stopping rule).
+    A 64-column slice is solved by scikit-learn with the reference's arguments (src/ontf.py:79-86): the
+    GPU's objective is never above scikit-learn's.  The same slice sweep for sweep against the oracle's
+    coordinate descent; and columns are independent: the slice coded alone gives the same codes."""
+    from onmf_ontf_ndl_amd import Online_NTF
+    d, r, b = 1200, 100, 2048
+    rs = np.random.RandomState(32)
+    T = patch_tensor(rs, b)
+    ntf = Online_NTF(T, n_components=r, mode=2, learn_joint_dict=True, alpha=None)    # alpha = 2
+    X = host(ntf.unfold())
+    W, _, _ = warm_state(rs, d, r)
+    H = ntf.joint_sparse_code_tensor(X, W)
+    assert H.shape == (b, r) and H.min() >= 0 and ntf.last_sweeps <= 4000
+    sl = slice(1000, 1064)
+    Xs, Ws = X[:, sl], W.astype(np.float64)
+    H_sk = orc.lasso_nonneg_code(Xs, Ws, None, solver="sklearn")
+    f_gpu = orc.lasso_objective(Xs, Ws, H[sl].T, 2)
+    f_sk = orc.lasso_objective(Xs, Ws, H_sk.T, 2)
+    assert np.all(f_gpu <= f_sk * (1 + 1e-5) + 1e-7)
+    H_alone = ntf.joint_sparse_code_tensor(Xs, W)
+    assert relerr(H_alone, H[sl]) < 1e-4
+    fixed = Online_NTF(T, n_components=r, mode=2, learn_joint_dict=True, alpha=None, cd_tol=0.0,
+                       cd_max_sweeps=SWEEPS)
+    H_fix = fixed.joint_sparse_code_tensor(X, W)
+    H_cd = orc.lasso_nonneg_code(Xs, Ws, None, solver="cd", sweeps=SWEEPS, tol=-1.0)
+    assert relerr(H_fix[sl], H_cd) < TOL_H
+
+
+def test_c3_ntf_train_dict_single_against_oracle(eng, orc):
+    """train_dict_single on a (400, 3, 300) tensor, mode 2 / joint (d=1200), r=100, 3 steps of 100
+    subsampled columns with carried aggregates (src/ontf.py:224-236), same NumPy random stream as the
+    oracle class, the coder sweep for sweep on both sides."""
+    from onmf_ontf_ndl_amd import Online_NTF
+    rs = np.random.RandomState(33)
+    T = patch_tensor(rs, 300)
+    r = 100
+    kw = dict(n_components=r, iterations=4, batch_size=100, mode=2, learn_joint_dict=True, alpha=1.0,
+              subsample=True)
+    np.random.seed(8)
+    W, A, B, code = Online_NTF(T, cd_tol=0.0, cd_max_sweeps=SWEEPS, **kw).train_dict_single()
+    np.random.seed(8)
+    W_o, A_o, B_o, _ = orc.OracleOnlineNTF(T.astype(np.float64), solver="cd", cd_sweeps=SWEEPS, cd_tol=-1.0,
+                                           **kw).train_dict_single()
+    assert W.shape == (1200, r) and A.shape == (r, r) and B.shape == (r, 1200)
+    assert W.min() >= 0 and np.linalg.norm(W, axis=0).max() <= 1 + 1e-5
+    assert relerr(W, W_o) < TOL_W
+    assert relerr(A, A_o) < 5e-5 and relerr(B, B_o) < 5e-5
+
+
+def test_exact_cd_in_chunks(eng, orc):
+    """onmf_sparse_code in exact coordinate-descent mode runs chunks of 8, 16, 32, 64, 64, ... sweeps per
+    launch and tests the batch's relative change on the last sweep of each chunk."""
+    import torch
+    from onmf_ontf_ndl_amd import _lib
+    rs = np.random.RandomState(5)
+    d, r, b = 300, 40, 700
+    X = f32(rs, d, b)
+    W, _, _ = warm_state(rs, d, r)
+    Xd, Wd, H0 = eng.dev(X), eng.dev(W), eng.zeros(r, b)
+    # 120 = 8 + 16 + 32 + 64 sweeps, tolerance 0: four launches, against the oracle sweep for sweep
+    H1, sweeps, dist = eng.sparse_code(Xd, Wd, H0=H0, alpha=0.3, sub_iter=120, stopping_diff=0.0,
+                                       mode=_lib.CODER_EXACT_CD)
+    assert sweeps == 120
+    assert [i for i in range(120) if np.isfinite(dist[i])] == [7, 23, 55, 119]
+    H_cd = orc.lasso_nonneg_code(X.astype(np.float64), W.astype(np.float64), 0.3, solver="cd", sweeps=120,
+                                 tol=-1.0).T
+    assert relerr(host(H1), H_cd) < TOL_H
+    # the per-column form, same sweeps: the same arithmetic
+    H2 = eng.sparse_code_each(Xd, Wd, H0=H0, alpha=0.3, sub_iter=120, stopping_diff=0.0,
+                              mode=_lib.CODER_EXACT_CD)
+    assert relerr(host(H2), host(H1)) < 1e-6
+    # a tolerance ends the loop at the first chunk whose last sweep moved less
+    H3, s3, d3 = eng.sparse_code(Xd, Wd, H0=H0, alpha=0.3, sub_iter=4000, stopping_diff=1e-3,
+                                 mode=_lib.CODER_EXACT_CD)
+    tested = [v for v in d3 if np.isfinite(v)]
+    assert s3 in (8, 24, 56) or (s3 >= 120 and (s3 - 120) % 64 == 0)
+    assert tested[-1] <= 1e-3 and all(v > 1e-3 for v in tested[:-1])
+    # one column, and a batch that leaves the tile kernel's range (r > 256: one launch per sweep)
+    H4, s4, _ = eng.sparse_code(Xd[:, :1].contiguous(), Wd, H0=eng.zeros(r, 1), alpha=0.3, sub_iter=24,
+                                stopping_diff=0.0, mode=_lib.CODER_EXACT_CD)
+    assert s4 == 24 and torch.isfinite(H4).all()
+
+
+def test_bad_column_index_raises_like_numpy(eng):
+    rs = np.random.RandomState(1)
+    X = eng.dev(f32(rs, 5, 20))
+    with pytest.raises(IndexError):
+        eng.gather_columns(X, np.array([0, 20]))
+    with pytest.raises(IndexError):
+        eng.gather_columns(X, np.array([-21, 3]))
+    got = host(eng.gather_columns(X, np.array([-1, 0])))
+    np.testing.assert_array_equal(got, host(X)[:, [-1, 0]])
+    code = eng.zeros(3, 20)
+    with pytest.raises(IndexError):
+        eng.code_accumulate(code, np.array([25]), eng.zeros(3, 1))
+
+
+def test_entry_points_leave_the_callers_device_alone(eng):
+    """Every entry point makes its context's device current and puts the caller's back."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        # one GPU: the guard has nothing to restore; the call path is exercised by every other test
+        assert torch.cuda.current_device() == eng.index
+        return
+    from onmf_ontf_ndl_amd.engine import get_engine
+    other = get_engine("cuda:1")
+    torch.cuda.set_device(0)
+    W = other.update_dict(other.zeros(8, 2) + 1, other.zeros(2, 2), other.zeros(2, 8))
+    assert torch.cuda.current_device() == 0 and W.device.index == 1

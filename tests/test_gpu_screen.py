@@ -164,12 +164,27 @@ def test_a_timed_out_one_launch_solve_is_redone_launch_by_launch(eng):
     ref = eng.sparse_code(X, W, H0=H0, stopping_diff=0.01)
     eng.set_option(PERSISTENT, 1)
     eng.set_option(8, -1)
+    before = eng.counters()
+    import warnings
     try:
-        got = eng.sparse_code(X, W, H0=H0, stopping_diff=0.01)
-        again = eng.sparse_code(X, W, H0=H0, stopping_diff=0.01)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")      # the engine warns once about the first timeout
+            got = eng.sparse_code(X, W, H0=H0, stopping_diff=0.01)
+            again = eng.sparse_code(X, W, H0=H0, stopping_diff=0.01)
     finally:
         eng.set_option(8, 2000)
-        eng.set_option(PERSISTENT, 1)
+        eng.set_option(PERSISTENT, 1)            # (also ends the rest the one-launch mode was sent to)
     for out in (got, again):
         assert out[1] == ref[1]
         assert torch.equal(out[0], ref[0])
+    # the event is visible to the caller: counted, and the following solve ran launch by launch
+    after = eng.counters()
+    assert after["sweep_timeouts"] == before["sweep_timeouts"] + 1
+    assert after["fallback_solves"] >= before["fallback_solves"] + 2
+    # with the rest over, a one-launch solve works again
+    eng.get_profile()
+    eng.set_option(1, 1)
+    third = eng.sparse_code(X, W, H0=H0, stopping_diff=0.01)
+    _, launches = eng.get_profile()
+    eng.set_option(1, 0)
+    assert torch.equal(third[0], ref[0]) and launches <= 2
