@@ -292,8 +292,9 @@ double onmf_host_lambda_max(const float* S_host, int n);
  *                          fits the chip's CUs; 0: one launch per sweep.
  *   ONMF_OPT_SPIN_LIMIT_MS bound, in milliseconds, of the waits of workgroups for each other - a
  *                          one-launch solve's, and the dictionary pass's for d > 1024 (default 2000;
- *                          negative: give up at the first look, which exercises the recovery paths -
- *                          every kernel still ends normally).  After a timeout the solve is run again
+ *                          -1: give up at the first look if what is waited for is not there yet; -2: give
+ *                          up at the first look in any case, which exercises the recovery paths - every
+ *                          kernel still ends normally).  After a timeout the solve is run again
  *                          with one launch per sweep, and so are the next 64 solves (128 after the next
  *                          timeout, and so on); then the one-launch mode is tried again.  The one-launch
  *                          mode assumes that one workgroup per CU is resident at once, which holds when

@@ -282,7 +282,8 @@ int onmf_set_option(onmf_ctx* c, int key, int value) {
             c->persistent_hold = 0;
             return ONMF_OK;
         case ONMF_OPT_SPIN_LIMIT_MS:
-            c->spin_limit = value < 0 ? -1LL : (long long)value * 100000LL;      // 100 MHz ticks
+            c->spin_limit = value == -2 ? SPIN_FORCE_TIMEOUT
+                                        : value < 0 ? -1LL : (long long)value * 100000LL;      // 100 MHz ticks
             return ONMF_OK;
         default: return onmf_fail(c, ONMF_ERR_ARG, "onmf_set_option: unknown key %d", key);
     }
@@ -505,7 +506,10 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
         const bool persistent = c->persistent_sweeps && c->persistent_hold == 0 && fits && !second_try;
         int start = 0;
         while (start < sub_iter) {
-            const ScreenDev sc = {base, start, (float)tol, (float)rank_cap, c->spin_limit /* 2 s */};
+            // (with one launch per sweep every count is complete before the launch that reads it starts:
+            // the forced timeout of the tests applies to one-launch solves only)
+            const long long spin = (!persistent && c->spin_limit == SPIN_FORCE_TIMEOUT) ? -1LL : c->spin_limit;
+            const ScreenDev sc = {base, start, (float)tol, (float)rank_cap, spin /* 2 s by default */};
             int i = start;
             // When the probes are due for a power step, it is taken on the move of the SECOND sweep (the
             // first one is the jump away from the random start; the later moves resemble each other

@@ -228,6 +228,9 @@ static_assert(ScreenLayout::SETS % 2 == 0 && ScreenLayout::SETSZ % 2 == 0 && Scr
                   ScreenLayout::CWY % 2 == 0,
               "double alignment");
 constexpr int SCREEN_FLAG_TIMEOUT = 4;     // a workgroup gave up waiting for the others
+// spin limit that makes every bounded wait between workgroups give up at its first look, whether or
+// not what it waits for is there already (ONMF_OPT_SPIN_LIMIT_MS = -2): exercises the recovery paths
+constexpr long long SPIN_FORCE_TIMEOUT = -2LL;
 
 #if defined(__HIPCC__)
 // The three-way verdict of one sweep from its by-products (see screen.hip).  Deterministic: every

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(64) void dict_pass_kernel(int d, int r, int nwg,
                     if (g < nwg) {
                         const u64 x = __hip_atomic_load(&granules[(size_t)j * nwg + g],
                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        ok = (unsigned)(x >> 32) == (unsigned)(j + 1);
+                        ok = (unsigned)(x >> 32) == (unsigned)(j + 1) && spin_limit != SPIN_FORCE_TIMEOUT;
                         val = __uint_as_float((unsigned)x);
                     }
                     if (__all(ok) || dead) break;
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(256) void dict_panel_kernel(int d, int r, int lda,
                     if (lane < nwg) {
                         const u64 x = __hip_atomic_load(&granules[(size_t)j * nwg + lane], __ATOMIC_RELAXED,
                                                         __HIP_MEMORY_SCOPE_AGENT);
-                        ok = (unsigned)(x >> 32) == (unsigned)(j + 1);
+                        ok = (unsigned)(x >> 32) == (unsigned)(j + 1) && spin_limit != SPIN_FORCE_TIMEOUT;
                         val = __uint_as_float((unsigned)x);
                     }
                     if (__all(ok)) break;

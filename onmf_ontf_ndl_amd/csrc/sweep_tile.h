@@ -210,7 +210,11 @@ __global__ __launch_bounds__(1024 / CT) void sweep_tile_kernel(
                     for (;;) {
                         // (the sums are read only after the count has been seen complete: they were
                         // all in place before its last increment)
-                        if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (int)gridDim.x) break;
+                        // (a limit of SPIN_FORCE_TIMEOUT makes the wait fail even when the count is complete:
+                        // the host's way to exercise the recovery path)
+                        if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (int)gridDim.x &&
+                            sc.spin_limit != SPIN_FORCE_TIMEOUT)
+                            break;
                         if (wall_clock64() - t0 > sc.spin_limit) {        // wave-uniform (one clock value)
                             verdict = SCREEN_FLAG_TIMEOUT;
                             break;

@@ -163,7 +163,7 @@ def test_a_timed_out_one_launch_solve_is_redone_launch_by_launch(eng):
     eng.set_option(PERSISTENT, 0)
     ref = eng.sparse_code(X, W, H0=H0, stopping_diff=0.01)
     eng.set_option(PERSISTENT, 1)
-    eng.set_option(8, -1)
+    eng.set_option(8, -2)                        # every wait gives up at its first look
     before = eng.counters()
     import warnings
     try:
