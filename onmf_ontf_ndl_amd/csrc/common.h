@@ -186,6 +186,8 @@ int launch_sweep_each(onmf_ctx* c, int r, int b, const float* Gm, const float* C
                       int exact_cd, int sub_iter, EachStop es, hipStream_t s);
 int launch_sweep_tile_each(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm, float* H, float alpha,
                            int exact_cd, int sub_iter, EachStop es, hipStream_t s);
+int launch_sweep_tile_each4(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm, float* H, float alpha,
+                            int exact_cd, int sub_iter, EachStop es, hipStream_t s);
 int sweep_tile_workgroups(int b);
 bool sweep_tile_covers(int r, int b);
 

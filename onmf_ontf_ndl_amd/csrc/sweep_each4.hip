@@ -1,22 +1,15 @@
-// Per-column stopping instantiations of the tile sweep kernel (one tile per wave, no probes).
+// Per-column stopping instantiations of the tile sweep kernel with 4 waves (64 columns) per workgroup.
 #include "sweep_tile.h"
 
-int launch_sweep_tile_each(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm, float* H, float alpha,
+int launch_sweep_tile_each4(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm, float* H, float alpha,
                            int exact_cd, int sub_iter, EachStop es, hipStream_t s) {
     const int nb = (r + 15) / 16;
-    // few columns: workgroups of 4 waves (64 columns), one per CU, so that the batch spreads over the chip
-    if (c->cu_count == 0) {
-        int cus = 0;
-        HIP_TRY(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
-        c->cu_count = cus;
-    }
-    if ((b + 63) / 64 <= c->cu_count) return launch_sweep_tile_each4(c, r, b, Gm, Cm, H, alpha, exact_cd, sub_iter, es, s);
     float* hb[3] = {H, H, H};
     ScreenDev none = {};
     int groups = 0;
 #define EACH_CASE(NBV, HALFV)                                                                              \
     case NBV:                                                                                              \
-        return run_tile<NBV, HALFV, false, 1, true>(c, r, b, Gm, Cm, hb, alpha, exact_cd, 0, sub_iter,     \
+        return run_tile<NBV, HALFV, false, 1, true, 4>(c, r, b, Gm, Cm, hb, alpha, exact_cd, 0, sub_iter,     \
                                                     nullptr, &groups, none, s, es)
     switch (nb) {
         EACH_CASE(1, false);

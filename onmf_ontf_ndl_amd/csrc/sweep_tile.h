@@ -76,16 +76,21 @@ __device__ __forceinline__ float row_sum16(float x) {
 // norms.  A column that has stopped runs with step 0 (exact no-op); a wave whose 16 columns have all
 // stopped skips the arithmetic.  Nothing is exchanged between workgroups, H is loaded once and stored
 // once (in place is fine), and es.sweeps receives the number of sweeps each column ran.
-template <int NB, bool HALF, bool PROBE, int CT, bool EACH = false>
-__global__ __launch_bounds__(1024 / CT) void sweep_tile_kernel(
+//
+// WPG = waves per workgroup (16 / CT by default: 256 columns per workgroup).  The per-column mode also
+// comes with 4 waves (64 columns) per workgroup: a batch of a few thousand columns then spreads over
+// that many more CUs with one wave per SIMD each, instead of four waves sharing every SIMD's matrix
+// pipe on a few CUs while the rest of the chip idles.
+template <int NB, bool HALF, bool PROBE, int CT, bool EACH = false, int WPG = 16 / CT>
+__global__ __launch_bounds__(64 * WPG) void sweep_tile_kernel(
     int r, int b, const float* __restrict__ Gm, const float* __restrict__ Cm, float* hb0, float* hb1,
     float* hb2, float alpha, int exact_cd, int k_first, int k_count, double* __restrict__ stats,
     ScreenDev sc, EachStop es) {
     static_assert(!EACH || (!PROBE && CT == 1), "per-column stopping: plain kernel, one tile per wave");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NBLK = HALF ? NB * (NB + 1) / 2 : NB * NB;
-    constexpr int NT = 1024 / CT;          // threads per workgroup
-    constexpr int WAVES = NT / 64;
+    constexpr int NT = 64 * WPG;           // threads per workgroup
+    constexpr int WAVES = WPG;
     float* Gs = lds;                       // NBLK swizzled 16x16 blocks of Gm
     float* steps = lds + NBLK * 256;       // 16*NB step sizes of the current sweep (0 for padded rows)
     float* gdiag = steps + 16 * NB;        // diagonal of Gm
@@ -503,7 +508,7 @@ __global__ __launch_bounds__(1024 / CT) void sweep_tile_kernel(
     }
 }
 
-template <int NB, bool HALF, bool PROBE, int CT, bool EACH = false>
+template <int NB, bool HALF, bool PROBE, int CT, bool EACH = false, int WPG = 16 / CT>
 int run_tile(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm, float* const* hb, float alpha,
              int exact_cd, int k_first, int k_count, double* stats, int* n_groups, const ScreenDev& sc,
              hipStream_t s, EachStop es = EachStop{}) {
@@ -511,11 +516,13 @@ int run_tile(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm, float*
     constexpr size_t lds = sizeof(float) * ((size_t)NBLK * 256 + 2 * NB * 16 + (PROBE ? (NB * 256 + 16 + 4 + 4) : 0));
     static_assert(lds <= 160 * 1024, "Gm blocks do not fit the LDS");
     static LdsLimit lim;
-    ONMF_TRY(onmf_raise_lds_limit(c, lim, (const void*)sweep_tile_kernel<NB, HALF, PROBE, CT, EACH>, lds));
-    constexpr int NT = 1024 / CT;
-    const int wgs = (b + TILE_COLS_PER_WG - 1) / TILE_COLS_PER_WG;
-    *n_groups = wgs * (NT / 64);
-    hipLaunchKernelGGL((sweep_tile_kernel<NB, HALF, PROBE, CT, EACH>), dim3(wgs), dim3(NT), lds, s, r, b, Gm, Cm,
+    ONMF_TRY(onmf_raise_lds_limit(c, lim, (const void*)sweep_tile_kernel<NB, HALF, PROBE, CT, EACH, WPG>, lds));
+    constexpr int NT = 64 * WPG;
+    constexpr int COLS = 16 * CT * WPG;    // columns per workgroup
+    static_assert(WPG != 16 / CT || COLS == TILE_COLS_PER_WG, "the default geometry is 256 columns per workgroup");
+    const int wgs = (b + COLS - 1) / COLS;
+    *n_groups = wgs * WPG;
+    hipLaunchKernelGGL((sweep_tile_kernel<NB, HALF, PROBE, CT, EACH, WPG>), dim3(wgs), dim3(NT), lds, s, r, b, Gm, Cm,
                        hb[0], hb[1], hb[2], alpha, exact_cd, k_first, k_count, stats, sc, es);
     HIP_TRY(c, hipGetLastError());
     return ONMF_OK;

@@ -293,6 +293,28 @@ def test_exact_cd_in_chunks(eng, orc):
     assert s4 == 24 and torch.isfinite(H4).all()
 
 
+def test_per_column_solver_in_small_and_large_batches(eng):
+    """The per-column solver picks workgroups of 64 columns for small batches and of 256 for large ones:
+    300 columns coded alone (64 per workgroup) and inside a batch of 70 000 (256 per workgroup) get the
+    same codes (to the rounding of W^T X, which a small and a large product sum in different orders) and
+    the same sweep counts for all but a few borderline columns."""
+    import torch
+    from onmf_ontf_ndl_amd import _lib
+    d, r, b = 147, 100, 70000
+    g = torch.Generator(device=eng.device).manual_seed(3)
+    X = torch.rand(d, b, device=eng.device, generator=g)
+    W = eng.update_dict(torch.rand(d, r, device=eng.device, generator=g), eng.zeros(r, r), eng.zeros(r, d))
+    H0 = torch.rand(r, b, device=eng.device, generator=g)
+    for mode, alpha, tol, iters in ((_lib.CODER_DAMPED, 1.0, 0.01, 10), (_lib.CODER_EXACT_CD, 0.5, 1e-3, 200)):
+        Hb, sb = eng.sparse_code_each(X, W, H0=H0, alpha=alpha, sub_iter=iters, stopping_diff=tol, mode=mode,
+                                      want_sweeps=True)
+        sl = slice(31000, 31300)
+        Hs, ss = eng.sparse_code_each(X[:, sl].contiguous(), W, H0=H0[:, sl].contiguous(), alpha=alpha,
+                                      sub_iter=iters, stopping_diff=tol, mode=mode, want_sweeps=True)
+        assert relerr(host(Hs), host(Hb[:, sl])) < 1e-4
+        assert int((ss != sb[sl]).sum()) <= 6
+
+
 def test_bad_column_index_raises_like_numpy(eng):
     rs = np.random.RandomState(1)
     X = eng.dev(f32(rs, 5, 20))

@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Condense the rocprofv3 --pmc passes that tools/run_pmc.sh left under a directory into one JSON per
+kernel family: per counter the mean over that kernel's dispatches, plus the derived figures the
+roofline discussion uses.  Usage: python3 tools/pmc_summary.py gpurun_out/<dir> profiles/r02_pmc"""
+import csv
+import glob
+import hashlib
+import json
+import os
+import sys
+
+CU = 256          # compute units of an MI355X
+PICK = {          # family -> (substring of the kernel name, passes that ran it)
+    "sweep": ("sweep_tile_kernel", ["sweep_sq1", "sweep_sq2", "sweep_fetch", "sweep_write"]),
+    "gemm_tt": ("gemm_f32_kernel<true, true>", ["gemm_sq1", "gemm_sq2", "gemm_fetch", "gemm_write"]),
+    "gemm_ff": ("gemm_f32_kernel<false, false>", ["gemm_sq1", "gemm_sq2", "gemm_fetch", "gemm_write"]),
+}
+
+
+def read_pass(path):
+    rows = []
+    for f in glob.glob(os.path.join(path, "**", "*counter_collection.csv"), recursive=True):
+        with open(f, newline="") as fh:
+            rows += list(csv.DictReader(fh))
+    return rows
+
+
+def main():
+    src, out = sys.argv[1], sys.argv[2]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for fam, (needle, passes) in PICK.items():
+        rec = {"kernel_name_contains": needle, "counters": {}, "dispatches": {}}
+        for p in passes:
+            rows = [r for r in read_pass(os.path.join(src, p)) if needle in r["Kernel_Name"]]
+            if not rows:
+                continue
+            # the longest-running variant of the family (largest grid x most dispatches) is the one of interest
+            by = {}
+            for r in rows:
+                by.setdefault(r["Counter_Name"], {}).setdefault(r["Kernel_Name"], {}).setdefault(
+                    r["Dispatch_Id"], 0.0)
+                by[r["Counter_Name"]][r["Kernel_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
+            for cname, kernels in by.items():
+                kname = max(kernels, key=lambda k: sum(kernels[k].values()))
+                vals = list(kernels[kname].values())
+                rec["counters"][cname] = sum(vals) / len(vals)
+                rec["dispatches"][cname] = len(vals)
+                rec["kernel"] = kname
+        c = rec["counters"]
+        d = {}
+        if "SQ_INSTS_MFMA" in c and "SQ_INSTS_VALU" in c:
+            d["valu_instructions_per_mfma"] = (c["SQ_INSTS_VALU"] - c["SQ_INSTS_MFMA"]) / c["SQ_INSTS_MFMA"] \
+                if c["SQ_INSTS_VALU"] > c["SQ_INSTS_MFMA"] else c["SQ_INSTS_VALU"] / c["SQ_INSTS_MFMA"]
+            d["note_valu"] = "SQ_INSTS_VALU counts MFMA instructions too when it exceeds SQ_INSTS_MFMA; the ratio is of the others"
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
+            d["mfma_busy_pct"] = 100.0 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] * CU * 4)
+            d["note_busy"] = "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 256 CUs x 4 SIMDs)"
+        if "SQ_LDS_BANK_CONFLICT" in c and "SQ_INSTS_LDS" in c and c["SQ_INSTS_LDS"]:
+            d["lds_bank_conflict_cycles_per_lds_instruction"] = c["SQ_LDS_BANK_CONFLICT"] / c["SQ_INSTS_LDS"]
+        if "FETCH_SIZE" in c:
+            d["hbm_read_bytes_per_dispatch_corrected"] = 2.0 * 1024.0 * c["FETCH_SIZE"]
+            d["note_fetch"] = "FETCH_SIZE is in KiB and reports half of the bytes on gfx950: doubled"
+        if "WRITE_SIZE" in c:
+            d["hbm_write_bytes_per_dispatch"] = 1024.0 * c["WRITE_SIZE"]
+        rec["derived"] = d
+        srcs = {"sweep": "sweep_tile.h", "gemm_tt": "gemm.hip", "gemm_ff": "gemm.hip"}[fam]
+        with open(os.path.join(root, "onmf_ontf_ndl_amd", "csrc", srcs), "rb") as fh:
+            rec["kernel_source"] = srcs
+            rec["kernel_source_sha256"] = hashlib.sha256(fh.read()).hexdigest()
+        with open("%s_%s.json" % (out, fam), "w") as fh:
+            json.dump(rec, fh, indent=1)
+        print(fam, json.dumps(rec["derived"]))
+
+
+if __name__ == "__main__":
+    main()
