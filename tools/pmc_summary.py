@@ -43,6 +43,9 @@ def main():
             for cname, kernels in by.items():
                 kname = max(kernels, key=lambda k: sum(kernels[k].values()))
                 vals = list(kernels[kname].values())
+                rec.setdefault("all_dispatches", {})[cname] = vals
+                # the full-length launches only (a solve that refreshes its probes cuts its launch short)
+                vals = [v for v in vals if v >= 0.8 * max(vals)]
                 rec["counters"][cname] = sum(vals) / len(vals)
                 rec["dispatches"][cname] = len(vals)
                 rec["kernel"] = kname
@@ -53,8 +56,10 @@ def main():
                 if c["SQ_INSTS_VALU"] > c["SQ_INSTS_MFMA"] else c["SQ_INSTS_VALU"] / c["SQ_INSTS_MFMA"]
             d["note_valu"] = "SQ_INSTS_VALU counts MFMA instructions too when it exceeds SQ_INSTS_MFMA; the ratio is of the others"
         if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
-            d["mfma_busy_pct"] = 100.0 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] * CU * 4)
-            d["note_busy"] = "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 256 CUs x 4 SIMDs)"
+            # rocprofv3's MfmaUtil: sum of busy cycles over the SIMDs / (GRBM_GUI_ACTIVE of ONE XCD x SIMDs);
+            # the CSV holds GRBM_GUI_ACTIVE summed over the 8 XCDs
+            d["mfma_busy_pct"] = 100.0 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8.0 * CU * 4)
+            d["note_busy"] = "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 256 CUs x 4 SIMDs)"
         if "SQ_LDS_BANK_CONFLICT" in c and "SQ_INSTS_LDS" in c and c["SQ_INSTS_LDS"]:
             d["lds_bank_conflict_cycles_per_lds_instruction"] = c["SQ_LDS_BANK_CONFLICT"] / c["SQ_INSTS_LDS"]
         if "FETCH_SIZE" in c:
@@ -62,6 +67,19 @@ def main():
             d["note_fetch"] = "FETCH_SIZE is in KiB and reports half of the bytes on gfx950: doubled"
         if "WRITE_SIZE" in c:
             d["hbm_write_bytes_per_dispatch"] = 1024.0 * c["WRITE_SIZE"]
+        if fam == "sweep" and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            # launches of 2 sweeps (probe refresh) and of 10: per-sweep bytes from their difference
+            f_all, w_all = rec["all_dispatches"]["FETCH_SIZE"], rec["all_dispatches"]["WRITE_SIZE"]
+            short = lambda v: [x for x in v if x < 0.5 * max(v)]
+            full = lambda v: [x for x in v if x >= 0.8 * max(v)]
+            if short(f_all) and short(w_all):
+                mean = lambda v: sum(v) / len(v)
+                b2 = 2048.0 * mean(short(f_all)) + 1024.0 * mean(short(w_all))
+                b10 = 2048.0 * mean(full(f_all)) + 1024.0 * mean(full(w_all))
+                d["hbm_bytes_2_sweep_launch"] = b2
+                d["hbm_bytes_10_sweep_launch"] = b10
+                d["hbm_bytes_per_sweep_in_launch"] = (b10 - b2) / 8.0
+                d["hbm_bytes_first_read"] = b2 - 2.0 * (b10 - b2) / 8.0
         rec["derived"] = d
         srcs = {"sweep": "sweep_tile.h", "gemm_tt": "gemm.hip", "gemm_ff": "gemm.hip"}[fam]
         with open(os.path.join(root, "onmf_ontf_ndl_amd", "csrc", srcs), "rb") as fh:
