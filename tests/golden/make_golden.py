@@ -312,7 +312,48 @@ def g10_image():
          code_loose=np.hstack(codes_loose), sweeps_loose=np.array(sweeps_loose))
 
 
+def g11_renoir():
+    """The C1 configuration on real data: 10 x 10 grey patches of Data/renoir/0.jpg, r = 16, 1000 patches
+    per driver iteration (iterations=2 each: one step), state carried - the first 16 iterations of the
+    100-iteration stream whose step index 2 stops after 4 sweeps.  The patches are stored as the image's
+    own uint8 values (X = patches / 255, as image_reconstruction.py:88 scales the image); the corner draws
+    use NumPy's global stream, which the replaying test repeats to stay in step with the H0 draws."""
+    from PIL import Image
+    np.random.seed(0)
+    img8 = np.asarray(Image.open(os.path.join(REF, "Data", "renoir", "0.jpg")).convert("L"))
+    data = img8 / 255
+    k, r, nb, outer = 10, 16, 1000, 16
+    W = agg = None
+    hist = 0
+    patches, sweeps, dists = [], [], []
+    for _ in range(outer):
+        a = np.random.randint(0, data.shape[0] - k, size=nb)
+        c = np.random.randint(0, data.shape[1] - k, size=nb)
+        P8 = np.stack([img8[i:i + k, j:j + k].reshape(-1) for i, j in zip(a, c)], axis=1)
+        X = np.stack([data[i:i + k, j:j + k].reshape(-1) for i, j in zip(a, c)], axis=1)
+        assert np.array_equal(P8 / 255, X)
+        nmf = Online_NMF(X, n_components=r, iterations=2, batch_size=nb, ini_dict=W, ini_agg=agg,
+                         history=hist, subsample=False)
+        with NormTap() as tap:
+            W, agg, _ = nmf.train_dict()
+        hist = nmf.history
+        patches.append(P8)
+        d_ = tap.dists()
+        sweeps.append(len(d_))
+        dists.append(np.pad(d_, (0, 10 - len(d_)), constant_values=np.nan))
+    nmf = Online_NMF(X, n_components=r)
+    Hl = nmf.sparse_code(X, W)
+    resid = np.linalg.norm(X - W @ Hl) / np.linalg.norm(X)
+    save("g11_renoir", patches=np.stack(patches).astype(np.uint8), image_shape=np.array(data.shape),
+         sweeps=np.array(sweeps), dists=np.stack(dists), W=W, A=agg[0], B=agg[1], hist=np.float64(hist),
+         H_last=Hl, resid=np.float64(resid))
+    print("g11: sweeps", sweeps, "resid", resid)
+
+
 if __name__ == "__main__":
-    for fn in (g1_code, g2_dict, g3_steps, g4_train_warm, g5_subsample, g6_full_code,
-               g7_beta_alpha, g8_stream, g9_lasso, g10_image):
-        fn()
+    cases = (g1_code, g2_dict, g3_steps, g4_train_warm, g5_subsample, g6_full_code,
+             g7_beta_alpha, g8_stream, g9_lasso, g10_image, g11_renoir)
+    want = set(sys.argv[1:])
+    for fn in cases:
+        if not want or fn.__name__.split("_")[0] in want:
+            fn()

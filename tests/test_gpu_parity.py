@@ -281,6 +281,35 @@ def test_g8_stream_of_warm_restarts(eng):
     assert abs(resid - g["resid"]) < 1e-5
 
 
+def test_g11_renoir_stream_through_class_surface(eng):
+    """BASELINE configs[0] on real data: 10 x 10 grey patches of the reference's Data/renoir/0.jpg, r = 16,
+    1000 patches per driver iteration, 16 iterations with (W, aggregates, history) carried through the
+    constructor as the reference's drivers do.  Everything random comes from NumPy's global stream in the
+    reference's order; the step with index 2 must stop after 4 sweeps like the reference's."""
+    from onmf_ontf_ndl_amd import Online_NMF
+    g = load_golden("g11_renoir")
+    k, r, nb = 10, 16, 1000
+    np.random.seed(0)
+    W = agg = None
+    hist = 0
+    sweeps = []
+    for it in range(g["patches"].shape[0]):
+        np.random.randint(0, g["image_shape"][0] - k, size=nb)      # the sampler's corner draws
+        np.random.randint(0, g["image_shape"][1] - k, size=nb)
+        X = g["patches"][it] / 255
+        nmf = Online_NMF(X, n_components=r, iterations=2, batch_size=nb, ini_dict=W, ini_agg=agg,
+                         history=hist, subsample=False)
+        W, agg, _ = nmf.train_dict()
+        hist = nmf.history
+        sweeps.append(nmf.last_sweeps)
+    assert sweeps == list(g["sweeps"]) and sweeps[2] == 4
+    assert relerr(W, g["W"]) < TOL_W
+    assert relerr(agg[0], g["A"]) < 5e-5 and relerr(agg[1], g["B"]) < 5e-5
+    assert hist == g["hist"]
+    H = Online_NMF(X, n_components=r).sparse_code(X, W)
+    assert abs(np.linalg.norm(X - W @ H) / np.linalg.norm(X) - g["resid"]) < 1e-5
+
+
 # ------------------------------------------------------------------------------------------
 # against the oracle on seeded inputs (sizes the oracle finishes in seconds)
 # ------------------------------------------------------------------------------------------

@@ -163,6 +163,35 @@ def test_g8_stream_with_injected_draws():
     assert abs(resid - g["resid"]) < 1e-10
 
 
+def test_g11_renoir_stream_through_the_global_rng():
+    """The C1 configuration on real image patches (10 x 10 grey windows of the reference's
+    Data/renoir/0.jpg, stored as uint8), 16 driver iterations with carried state; the step with index 2
+    stops after 4 sweeps.  Replayed through NumPy's global generator in the reference's order: two corner
+    draws per iteration, the initial dictionary once, H0 per step."""
+    g = load_golden("g11_renoir")
+    k, r, nb = 10, 16, 1000
+    np.random.seed(0)
+    W = agg = None
+    hist = 0
+    sweeps = []
+    for it in range(g["patches"].shape[0]):
+        np.random.randint(0, g["image_shape"][0] - k, size=nb)      # the corner draws of the sampler
+        np.random.randint(0, g["image_shape"][1] - k, size=nb)
+        X = g["patches"][it] / 255
+        nmf = orc.OracleOnlineNMF(X, n_components=r, iterations=2, batch_size=nb, ini_dict=W, ini_agg=agg,
+                                  history=hist, subsample=False)
+        W, agg, _ = nmf.train_dict()
+        hist = nmf.history
+        sweeps.append(len(nmf.sweep_log[-1]))
+        np.testing.assert_allclose([v for _, v in nmf.sweep_log[-1]], g["dists"][it][:sweeps[-1]], rtol=1e-9)
+    assert sweeps == list(g["sweeps"]) and sweeps[2] == 4
+    assert relerr(W, g["W"]) < 1e-10 and relerr(agg[0], g["A"]) < 1e-10 and relerr(agg[1], g["B"]) < 1e-10
+    assert hist == g["hist"]
+    H = orc.OracleOnlineNMF(X, n_components=r).sparse_code(X, W)
+    assert relerr(H, g["H_last"]) < 1e-10
+    assert abs(np.linalg.norm(X - W @ H) / np.linalg.norm(X) - g["resid"]) < 1e-10
+
+
 @pytest.mark.parametrize("name,alpha", [("default2", None), ("a05", 0.5), ("a005", 0.05)])
 def test_g9_lasso_matches_sklearn_vectors(name, alpha):
     g = load_golden("g9_lasso")
