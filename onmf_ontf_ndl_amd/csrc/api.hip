@@ -60,126 +60,6 @@ int onmf_reserve_pinned(onmf_ctx* c, size_t bytes) {
     return ONMF_OK;
 }
 
-// ---------------------------------------------------------------------------------------------
-// largest eigenvalue of a symmetric PSD matrix: Lanczos with full re-orthogonalisation, the
-// tridiagonal's top eigenvalue by Sturm-sequence bisection; all in double.
-// ---------------------------------------------------------------------------------------------
-// number of eigenvalues of the symmetric tridiagonal (a, b) of order m that are < x (Sturm count)
-static int tridiag_below(const std::vector<double>& a, const std::vector<double>& b, int m, double x) {
-    int cnt = 0;
-    double q = a[0] - x;
-    if (q < 0) ++cnt;
-    for (int i = 1; i < m; ++i) {
-        if (q == 0.0) q = 1e-300;
-        q = a[i] - x - b[i - 1] * b[i - 1] / q;
-        if (q < 0) ++cnt;
-    }
-    return cnt;
-}
-
-// top eigenvalue by bisection; `floor` is a known lower bound of it (or -inf)
-static double tridiag_top(const std::vector<double>& a, const std::vector<double>& b, int m, double floor) {
-    if (m == 1) return a[0];
-    double lo = std::numeric_limits<double>::infinity(), hi = -lo;
-    for (int i = 0; i < m; ++i) {
-        const double off = (i > 0 ? std::fabs(b[i - 1]) : 0.0) + (i + 1 < m ? std::fabs(b[i]) : 0.0);
-        lo = std::min(lo, a[i] - off);
-        hi = std::max(hi, a[i] + off);
-    }
-    if (floor > lo && floor <= hi) lo = floor;
-    for (int it = 0; it < 200 && hi - lo > 1e-16 * std::max(std::fabs(hi), std::fabs(lo)); ++it) {
-        const double mid = 0.5 * (lo + hi);
-        if (tridiag_below(a, b, m, mid) >= m) hi = mid; else lo = mid;
-    }
-    return 0.5 * (lo + hi);
-}
-
-static inline double dot4(const double* x, const double* y, int n) {
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    int i = 0;
-    for (; i + 3 < n; i += 4) {
-        s0 += x[i] * y[i];
-        s1 += x[i + 1] * y[i + 1];
-        s2 += x[i + 2] * y[i + 2];
-        s3 += x[i + 3] * y[i + 3];
-    }
-    for (; i < n; ++i) s0 += x[i] * y[i];
-    return (s0 + s1) + (s2 + s3);
-}
-
-// `enough` > 0: return as soon as a Ritz value (always a lower bound of the top eigenvalue) reaches it.
-// The top Ritz value only grows from step to step; it is evaluated at every step while the basis is
-// small and every fourth step after that (its bisection costs as much as the step itself).
-static double lambda_max_impl(const float* S, int n, double enough) {
-    if (n <= 0) return 0.0;
-    if (n == 1) return (double)S[0];
-    double fro = 0.0;
-    for (size_t i = 0; i < (size_t)n * n; ++i) fro += (double)S[i] * S[i];
-    if (!(fro > 0.0)) return (fro == 0.0) ? 0.0 : std::numeric_limits<double>::quiet_NaN();
-    const int mmax = n;
-    std::vector<double> Sd((size_t)n * n), V((size_t)(mmax + 1) * n), w(n), al, be;
-    for (size_t i = 0; i < (size_t)n * n; ++i) Sd[i] = (double)S[i];
-    // deterministic start vector with a component along every coordinate
-    double nv = 0.0;
-    for (int i = 0; i < n; ++i) {
-        V[i] = 1.0 + 0.5 * std::sin(12.9898 * (i + 1));
-        nv += V[i] * V[i];
-    }
-    nv = std::sqrt(nv);
-    for (int i = 0; i < n; ++i) V[i] /= nv;
-    double theta = 0.0, prev = -1.0;
-    bool theta_current = false;
-    int calm = 0;
-    for (int j = 0; j < mmax; ++j) {
-        const double* vj = &V[(size_t)j * n];
-        for (int i = 0; i < n; ++i) w[i] = dot4(&Sd[(size_t)i * n], vj, n);
-        al.push_back(dot4(w.data(), vj, n));
-        for (int pass = 0; pass < 2; ++pass) {
-            for (int l = 0; l <= j; ++l) {
-                const double* vl = &V[(size_t)l * n];
-                const double c = dot4(w.data(), vl, n);
-                for (int i = 0; i < n; ++i) w[i] -= c * vl[i];
-            }
-        }
-        const double bn = std::sqrt(dot4(w.data(), w.data(), n));
-        const int m = j + 1;
-        const bool last = bn <= 1e-14 * std::sqrt(fro) || m == mmax;
-        theta_current = false;
-        if (enough > 0.0 && tridiag_below(al, be, m, enough) < m) {
-            // a Ritz value >= enough exists: report it
-            return tridiag_top(al, be, m, enough);
-        }
-        if (last) {
-            theta = tridiag_top(al, be, m, prev > 0.0 ? prev : -std::numeric_limits<double>::infinity());
-            theta_current = true;
-            break;
-        }
-        // Small matrices run all n steps (exact) and need the Ritz value only at the end.  Larger ones
-        // stop once it stagnates: from step 16 on, every fourth step, first asking with one Sturm count
-        // whether it has moved at all (the bisection costs as much as several steps).
-        if (n > 48 && m >= 16 && (m & 3) == 0) {
-            const bool moved = prev <= 0.0 || tridiag_below(al, be, m, prev * (1.0 + 1e-14)) < m;
-            if (moved) {
-                theta = tridiag_top(al, be, m, prev > 0.0 ? prev : -std::numeric_limits<double>::infinity());
-                calm = 0;
-                prev = theta;
-            } else {
-                theta = prev;
-                if (++calm >= 2 && m >= 24) {
-                    theta_current = true;
-                    break;
-                }
-            }
-        }
-        be.push_back(bn);
-        double* vn = &V[(size_t)(j + 1) * n];
-        for (int i = 0; i < n; ++i) vn[i] = w[i] / bn;
-    }
-    if (!theta_current) theta = tridiag_top(al, be, (int)al.size(), prev);
-    return theta;
-}
-
-double host_lambda_max(const float* S, int n) { return lambda_max_impl(S, n, 0.0); }
 
 // ---------------------------------------------------------------------------------------------
 // ABI
@@ -249,7 +129,8 @@ int onmf_destroy(onmf_ctx* c) {
     DeviceGuard guard(c->device);
     (void)hipDeviceSynchronize();
     DevBuf* bufs[] = {&c->slab, &c->cm, &c->gram, &c->hbuf[0], &c->hbuf[1], &c->stats, &c->small,
-                      &c->qt, &c->sync, &c->idx, &c->dbuf, &c->slab_side, &c->screen, &c->ddelta, &c->slab_prep};
+                      &c->qt, &c->sync, &c->idx, &c->dbuf, &c->slab_side, &c->screen, &c->ddelta, &c->slab_prep,
+                      &c->gstack};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (c->pinned) (void)hipHostFree(c->pinned);
@@ -345,6 +226,41 @@ static int exact_dist(onmf_ctx* c, int r, int b, const float* Hnew, const float*
     if (sigma_new_ub) *sigma_new_ub = -1.0;
     const size_t rb = (size_t)r * b;
     const size_t rr = (size_t)r * r;
+    if (2 * r <= 128) {
+        // Small r: the difference and the old code are stacked into one (2r x b) matrix whose Gram - ONE
+        // 128 x 128 output tile, one product launch and one reduction - holds both Gram matrices on its
+        // diagonal; one copy, one wait, then the two eigenvalues (the cheap half first, as below).
+        const int r2 = 2 * r;
+        ONMF_TRY(onmf_reserve(c, c->gstack, 2 * rb * sizeof(float), "stacked stop-test operands"));
+        ONMF_TRY(onmf_reserve(c, c->small, (size_t)r2 * r2 * sizeof(float), "stop-test Grams"));
+        ONMF_TRY(onmf_reserve_pinned(c, ((size_t)r2 * r2 + 2 * rr) * sizeof(float)));
+        float* St = (float*)c->gstack.p;
+        float* G = (float*)c->small.p;
+        ONMF_TRY(launch_sub_stack(St, Hnew, Hold, rb, s));
+        ONMF_TRY(launch_gemm(c, false, false, r2, r2, b, St, b, St, b, 1.f, 0.f, nullptr, G, r2, s));
+        HIP_TRY(c, hipMemcpyAsync(c->pinned, G, (size_t)r2 * r2 * sizeof(float), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        const float* hg = (const float*)c->pinned;
+        float* g1 = (float*)c->pinned + (size_t)r2 * r2;      // the two diagonal blocks, contiguous
+        float* g0 = g1 + rr;
+        for (int i = 0; i < r; ++i) {
+            std::memcpy(g1 + (size_t)i * r, hg + (size_t)i * r2, r * sizeof(float));
+            std::memcpy(g0 + (size_t)i * r, hg + (size_t)(r + i) * r2 + r, r * sizeof(float));
+        }
+        if (ub_old > 0.0 && tol > 0.0) {
+            const double need = (tol * ub_old) * (tol * ub_old) * (1.0 + 2e-4);   // margin: fp32 Gram rounding
+            const double th = host_lambda_max_enough(g1, r, need);
+            if (th >= need) {
+                *dist = std::sqrt(th) / ub_old;
+                return ONMF_OK;
+            }
+        }
+        const double l1 = host_lambda_max(g1, r);
+        const double l0 = host_lambda_max(g0, r);
+        *dist = std::sqrt(std::max(l1, 0.0)) / std::sqrt(std::max(l0, 0.0));
+        if (sigma_new_ub && l0 > 0.0 && l1 >= 0.0) *sigma_new_ub = (std::sqrt(l0) + std::sqrt(l1)) * (1.0 + 1e-5);
+        return ONMF_OK;
+    }
     ONMF_TRY(onmf_reserve(c, c->dbuf, rb * sizeof(float), "code difference"));
     ONMF_TRY(onmf_reserve(c, c->small, 2 * rr * sizeof(float), "stop-test Grams"));
     ONMF_TRY(onmf_reserve_pinned(c, 2 * rr * sizeof(float)));
@@ -358,7 +274,7 @@ static int exact_dist(onmf_ctx* c, int r, int b, const float* Hnew, const float*
         HIP_TRY(c, hipMemcpyAsync(c->pinned, G1, rr * sizeof(float), hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipStreamSynchronize(s));
         const double need = (tol * ub_old) * (tol * ub_old) * (1.0 + 2e-4);   // margin: fp32 Gram rounding
-        const double th = lambda_max_impl(hg, r, need);
+        const double th = host_lambda_max_enough(hg, r, need);
         if (th >= need) {
             *dist = std::sqrt(th) / ub_old;
             return ONMF_OK;
@@ -396,8 +312,11 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
     ONMF_TRY(onmf_reserve(c, c->hbuf[1], rb * sizeof(float), "code buffer"));
     const int max_groups = (b + 15) / 16 + 64;
     ONMF_TRY(onmf_reserve(c, c->stats, (size_t)max_groups * 2 * sizeof(double), "sweep statistics"));
-    ONMF_TRY(onmf_reserve_pinned(c, std::max((size_t)max_groups * 2 * sizeof(double),
-                                             (size_t)ScreenLayout::TOTAL * sizeof(float))));
+    // (large enough for everything a solve copies to the host, the full test's Gram matrices included:
+    // the staging area must not move while the verdict records in it are being read)
+    ONMF_TRY(onmf_reserve_pinned(c, std::max({(size_t)max_groups * 2 * sizeof(double),
+                                              (size_t)ScreenLayout::TOTAL * sizeof(float),
+                                              (size_t)6 * r * r * sizeof(float)})));
     float* Gm = (float*)c->gram.p;
     float* Cm = (float*)c->cm.p;
     // Gm = W^T W,  Cm = W^T X   (src/onmf.py:242-243).  Gm, the initial code and the screen state are
@@ -491,14 +410,14 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
         float* base = (float*)c->screen.p;
         const bool refresh_probes = c->screen_refresh_due || probes_new;
         double min_margin = 1e300;       // smallest (lower bound / tol) among the "continue" verdicts
-        bool undecided = false, posted = false;
+        bool undecided = false, posted = false, chain_clean = true;   // chain = one enqueue of sweeps + verdicts
         if (c->cu_count == 0) {
             int cus = 0;
             HIP_TRY(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
             c->cu_count = cus;
         }
         // (after a timeout the one-launch mode rests for persistent_backoff solves, then gets another try)
-        const bool fits = sweep_tile_workgroups(b) <= c->cu_count;
+        const bool fits = sweep_tile_workgroups(c, r, b, true) <= c->cu_count;
         if (fits && c->persistent_sweeps && c->persistent_hold > 0) {
             --c->persistent_hold;
             ++c->n_fallback_solves;
@@ -530,15 +449,17 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
                     if (i < sub_iter) ONMF_TRY(launch_screen_cw(c, base, r, b, buf[i % 3], i, s));
                 }
             }
-            const bool ahead = after && start == 0 && (rb & 3) == 0 && !c->screen_last_undecided;
+            // (the first enqueue of a solve does not run ahead when the previous solve needed the host:
+            // chances are this one does too, and the work enqueued here would run twice; once the host
+            // has settled a sweep, what follows is short and usually conclusive, so it does again)
+            const bool ahead = after && (rb & 3) == 0 && (start > 0 || !c->screen_last_undecided);
+            posted = false;
             if (ahead && behind_sweeps) ONMF_TRY((*behind_sweeps)());
             // a sweep evaluates the test of the one two sweeps back: the last two are still open
             ONMF_TRY(launch_screen_final(c, base, std::max(start, sub_iter - 2), sub_iter - 1, (float)tol,
                                          (float)rank_cap, s));
             HIP_TRY(c, hipMemcpyAsync(c->pinned, base + ScreenLayout::REC,
                                       (size_t)4 * SCREEN_MAX_SWEEPS * sizeof(float), hipMemcpyDeviceToHost, s));
-            // (not when the previous solve needed the host: chances are this one does too, and the work
-            // enqueued here would run twice)
             if (ahead) {
                 // the host waits for the records only; the follow-up work is already behind them
                 if (!c->ev_rec) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_rec, hipEventDisableTiming));
@@ -553,6 +474,7 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
             const float* rec = (const float*)c->pinned;
             int next_start = sub_iter;
             bool stop = false;
+            chain_clean = true;
             for (int i = start; i < sub_iter; ++i) {
                 const int code = (int)rec[4 * i + 2];     // 1 continue, 2 stop, 3 inconclusive
                 if (code == 0) {
@@ -589,8 +511,16 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
                     stop = true;
                     break;
                 }
+                if (i + 1 == sub_iter) {
+                    // The loop ends after this sweep whatever its test says (src/onmf.py:252: i < sub_iter):
+                    // nothing depends on the value, so it is not evaluated in full; the trace shows the
+                    // lower bound.
+                    if (dist_trace) dist_trace[i] = rec[4 * i + 0];
+                    continue;
+                }
                 double dist = nan;                        // bounds straddle tol: evaluate in full
                 undecided = true;
+                chain_clean = false;
                 // With several sweeps to go, both halves of the test are evaluated even where the cheap
                 // one would do: the exact sigma_max(H) they give makes the bounds of the sweeps that
                 // follow tight (H moves little from here on), which saves their host round trips.
@@ -614,7 +544,7 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
         // the next solve refreshes its probes if these left the bounds undecided or close to it
         c->screen_refresh_due = undecided || min_margin < 1.5;
         c->screen_last_undecided = undecided;
-        if (posted && !undecided) {      // the device put the result in H and the follow-up work stands
+        if (posted && chain_clean) {     // the device put the result in H and the follow-up work stands
             if (after_valid) *after_valid = true;
             if (sweeps_done) *sweeps_done = done;
             if (dist_trace)

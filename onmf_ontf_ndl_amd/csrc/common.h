@@ -45,6 +45,7 @@ struct onmf_ctx {
     std::vector<hipEvent_t> ev;     // pairs of events bracketing sweep launches
     int ev_used = 0;
     DevBuf dbuf;                    // H - H_prev for the exact stopping test (r x b)
+    DevBuf gstack;                  // small r: [H - H_prev ; H_prev] stacked (2r x b), one product for both Grams
     DevBuf screen;                  // stopping-test screen state (ScreenLayout)
     DevBuf slab_side;               // split-K slabs of products issued on the side stream
     hipStream_t side = nullptr;     // dictionary pass runs here, beside the code solve
@@ -188,7 +189,13 @@ int launch_sweep_tile_each(onmf_ctx* c, int r, int b, const float* Gm, const flo
                            int exact_cd, int sub_iter, EachStop es, hipStream_t s);
 int launch_sweep_tile_each4(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm, float* H, float alpha,
                             int exact_cd, int sub_iter, EachStop es, hipStream_t s);
-int sweep_tile_workgroups(int b);
+int launch_sweep_tile_ct2_small(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm, float* const* hb,
+                                float alpha, int exact_cd, int k_first, int k_count, double* stats,
+                                int* n_groups, hipStream_t s, const ScreenDev* screen);
+bool sweep_tile_small_covers(int r);
+// workgroups of a sweep launch (probing or not) for this shape: 256 columns each, or 64 each for the
+// small-workgroup probing kernel (small r, few columns)
+int sweep_tile_workgroups(onmf_ctx* c, int r, int b, bool probing);
 bool sweep_tile_covers(int r, int b);
 
 // Image <-> patch matrix (patches.hip).  corners: device int[2*b] (row, column) pairs, or null for the
@@ -365,6 +372,7 @@ int launch_scatter_add_last(onmf_ctx* c, int r, int n, float* code, const long l
                             const float* H, hipStream_t s);
 int launch_axpy(float* y, const float* x, float a, size_t n, hipStream_t s);
 int launch_sub(float* out, const float* a, const float* b, size_t n, hipStream_t s);
+int launch_sub_stack(float* out, const float* a, const float* b, size_t n, hipStream_t s);
 int launch_axpby(float* out, const float* old, float keep, const float* part, float w, size_t n, hipStream_t s);
 int launch_unfold3(int n0, int n1, int n2, const float* T, int mode, int transpose, float* out,
                    hipStream_t s);
@@ -374,3 +382,5 @@ int launch_surrogate_partials(int d, int r, const float* Q, const float* W, cons
 
 // host: largest eigenvalue of a symmetric PSD n x n matrix (row-major float), in double
 double host_lambda_max(const float* S, int n);
+// the same, returning early with any Ritz value >= enough (a lower bound of the eigenvalue) when enough > 0
+double host_lambda_max_enough(const float* S, int n, double enough);

@@ -79,6 +79,18 @@ __global__ __launch_bounds__(256) void sub_kernel(float* __restrict__ out, const
         out[i] = a[i] - b[i];
 }
 
+// out[0 .. n) = a - b and out[n .. 2n) = b: the two operands of the stopping test stacked, so that ONE
+// product of the stack with its own transpose holds both Gram matrices
+__global__ __launch_bounds__(256) void sub_stack_kernel(float* __restrict__ out, const float* __restrict__ a,
+                                                        const float* __restrict__ b, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const float bv = b[i];
+        out[i] = a[i] - bv;
+        out[n + i] = bv;
+    }
+}
+
 // last[j] = largest position p with idx[p] == j (or -1)
 __global__ __launch_bounds__(256) void last_pos_init_kernel(int* last, int n) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) last[i] = -1;
@@ -223,6 +235,12 @@ int launch_axpby(float* out, const float* old, float keep, const float* part, fl
 int launch_sub(float* out, const float* a, const float* b, size_t n, hipStream_t s) {
     if (n == 0) return ONMF_OK;
     hipLaunchKernelGGL(sub_kernel, dim3(grid_for(n)), dim3(256), 0, s, out, a, b, n);
+    return hipGetLastError() == hipSuccess ? ONMF_OK : ONMF_ERR_HIP;
+}
+
+int launch_sub_stack(float* out, const float* a, const float* b, size_t n, hipStream_t s) {
+    if (n == 0) return ONMF_OK;
+    hipLaunchKernelGGL(sub_stack_kernel, dim3(grid_for(n)), dim3(256), 0, s, out, a, b, n);
     return hipGetLastError() == hipSuccess ? ONMF_OK : ONMF_ERR_HIP;
 }
 

@@ -56,6 +56,9 @@ __global__ void screen_clear_flag_kernel(float* base, int k, float ub) {
     if (threadIdx.x == 0) {
         reinterpret_cast<int*>(base)[ScreenLayout::FLAG] = 0;
         base[ScreenLayout::UBH + k] = ub;
+        // the host settled sweep k - 1 as "continue": the device's own reading of the records
+        // (screen_finalize_kernel) must see it that way too
+        if (k > 0) base[ScreenLayout::REC + 4 * (k - 1) + 2] = 1.0f;
     }
 }
 
@@ -156,7 +159,8 @@ __global__ __launch_bounds__(64) void screen_final_kernel(float* base, int k_fro
 
 // After the last sweep of an enqueue: put the solve's result into the caller's buffer if it ended
 // elsewhere.  The verdict records say where it ended: sweeps 0..done-1 count, the result is in
-// buffer done % 3.  An inconclusive record means the host will finish the solve: nothing to do here.
+// buffer done % 3.  An inconclusive record (other than the last sweep's) means the host will finish the
+// solve: nothing to do here.
 __global__ __launch_bounds__(256) void screen_finalize_kernel(const float* base, int sub_iter, const float4* hb0,
                                                               const float4* hb1, const float4* hb2,
                                                               float4* __restrict__ dst, size_t n4) {
@@ -166,7 +170,9 @@ __global__ __launch_bounds__(256) void screen_finalize_kernel(const float* base,
         for (int i = 0; i < sub_iter; ++i) {
             const int code = (int)base[ScreenLayout::REC + 4 * i + 2];
             if (code == 2) { done = i + 1; break; }
-            if (code != 1) { undecided = 1; break; }
+            // (the last sweep's test decides nothing - the loop ends after it either way - so an
+            // inconclusive record there is as good as any)
+            if (code != 1 && !(code == 3 && i + 1 == sub_iter)) { undecided = 1; break; }
         }
         src_s = undecided ? -1 : done % 3;
     }

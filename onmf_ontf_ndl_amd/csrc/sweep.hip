@@ -134,7 +134,23 @@ bool sweep_tile_covers(int r, int b) {
     return (r + 15) / 16 <= 16 && (double)r * (double)b * 4.0 < 2147483000.0;
 }
 
-int sweep_tile_workgroups(int b) { return (b + 255) / 256; }
+static int cu_count(onmf_ctx* c) {
+    if (c->cu_count == 0) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess) c->cu_count = cus;
+    }
+    return c->cu_count;
+}
+
+// The small-workgroup probing kernel (64 columns per workgroup) when its grid still fits the chip in
+// one round - the condition for running all sweeps of a solve in one launch.
+static bool use_small_workgroups(onmf_ctx* c, int r, int b, bool probing) {
+    return probing && c->sweep_kernel == 0 && sweep_tile_small_covers(r) && (b + 63) / 64 <= cu_count(c);
+}
+
+int sweep_tile_workgroups(onmf_ctx* c, int r, int b, bool probing) {
+    return use_small_workgroups(c, r, b, probing) ? (b + 63) / 64 : (b + 255) / 256;
+}
 
 int launch_sweep(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm, float* const* hb,
                  float alpha, int exact_cd, int k_first, int k_count, double* stats, int* n_groups,
@@ -152,6 +168,9 @@ int launch_sweep(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm, fl
     // Column tiles per wave: option values 3 / 4 pin 1 / 2.  Otherwise 2 for the probing kernel
     // (twice the registers per lane: its extra state fits without spills, and half the LDS operand
     // traffic) and 1 for the plain one (4 waves per SIMD hide its shorter chain better).
+    if (use_small_workgroups(c, r, b, screen != nullptr))
+        return launch_sweep_tile_ct2_small(c, r, b, Gm, Cm, hb, alpha, exact_cd, k_first, k_count, stats, n_groups,
+                                           s, screen);
     if (c->sweep_kernel == 4 || (c->sweep_kernel != 3 && screen))
         return launch_sweep_tile_ct2(c, r, b, Gm, Cm, hb, alpha, exact_cd, k_first, k_count, stats, n_groups, s,
                                      screen);
