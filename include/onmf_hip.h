@@ -290,6 +290,12 @@ double onmf_host_lambda_max(const float* S_host, int n);
  *   ONMF_OPT_PERSISTENT_SWEEPS != 0 (default): with the screened stopping test, run all sweeps of
  *                          a solve in one launch when its grid (one workgroup per 256 columns)
  *                          fits the chip's CUs; 0: one launch per sweep.
+ *   ONMF_OPT_DEVICE_RESOLVE != 0: for r <= 64, when the previous solve needed a full evaluation of the
+ *                          stopping test, the next one-launch solve carries one round of device-side
+ *                          resolution (both Gram matrices and their top eigenvalues computed on the GPU,
+ *                          the sweeps continued from there) so that the host is not in the loop; 0
+ *                          (default: the kernel does not yet beat the host's round trip): the host
+ *                          evaluates every inconclusive test.  Same sweep counts and codes either way.
  *   ONMF_OPT_SPIN_LIMIT_MS bound, in milliseconds, of the waits of workgroups for each other - a
  *                          one-launch solve's, and the dictionary pass's for d > 1024 (default 2000;
  *                          -1: give up at the first look if what is waited for is not there yet; -2: give
@@ -309,6 +315,7 @@ double onmf_host_lambda_max(const float* S_host, int n);
 #define ONMF_OPT_DICT_KERNEL 6
 #define ONMF_OPT_PERSISTENT_SWEEPS 7
 #define ONMF_OPT_SPIN_LIMIT_MS 8
+#define ONMF_OPT_DEVICE_RESOLVE 9
 int onmf_set_option(onmf_ctx* ctx, int key, int value);
 /*
  * Event counters since onmf_create (no counterpart in the reference):
@@ -319,6 +326,7 @@ int onmf_set_option(onmf_ctx* ctx, int key, int value);
 #define ONMF_CNT_SWEEP_TIMEOUTS 1
 #define ONMF_CNT_DICT_TIMEOUTS 2
 #define ONMF_CNT_FALLBACK_SOLVES 3
+#define ONMF_CNT_DEVICE_RESOLVES 4   /* inconclusive stopping tests settled on the device (no host round trip) */
 int onmf_get_counter(onmf_ctx* ctx, int which, long long* value);
 /* Summed device time (ms) and number of sweep-kernel launches since the previous call. */
 int onmf_get_profile(onmf_ctx* ctx, double* sweep_ms, int* sweep_launches);

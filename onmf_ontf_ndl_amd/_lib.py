@@ -23,9 +23,11 @@ OPT_SCREEN_STOP = 5
 OPT_DICT_KERNEL = 6
 OPT_PERSISTENT_SWEEPS = 7
 OPT_SPIN_LIMIT_MS = 8
+OPT_DEVICE_RESOLVE = 9
 CNT_SWEEP_TIMEOUTS = 1
 CNT_DICT_TIMEOUTS = 2
 CNT_FALLBACK_SOLVES = 3
+CNT_DEVICE_RESOLVES = 4
 NDL_GLAUBER = 0
 NDL_PIVOT = 1
 

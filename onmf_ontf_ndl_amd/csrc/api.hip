@@ -130,7 +130,7 @@ int onmf_destroy(onmf_ctx* c) {
     (void)hipDeviceSynchronize();
     DevBuf* bufs[] = {&c->slab, &c->cm, &c->gram, &c->hbuf[0], &c->hbuf[1], &c->stats, &c->small,
                       &c->qt, &c->sync, &c->idx, &c->dbuf, &c->slab_side, &c->screen, &c->ddelta, &c->slab_prep,
-                      &c->gstack};
+                      &c->gstack, &c->rslab};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (c->pinned) (void)hipHostFree(c->pinned);
@@ -162,6 +162,7 @@ int onmf_set_option(onmf_ctx* c, int key, int value) {
             c->persistent_sweeps = value;
             c->persistent_hold = 0;
             return ONMF_OK;
+        case ONMF_OPT_DEVICE_RESOLVE: c->device_resolve = value; return ONMF_OK;
         case ONMF_OPT_SPIN_LIMIT_MS:
             c->spin_limit = value == -2 ? SPIN_FORCE_TIMEOUT
                                         : value < 0 ? -1LL : (long long)value * 100000LL;      // 100 MHz ticks
@@ -176,6 +177,7 @@ int onmf_get_counter(onmf_ctx* c, int which, long long* value) {
         case ONMF_CNT_SWEEP_TIMEOUTS: *value = c->n_sweep_timeouts; return ONMF_OK;
         case ONMF_CNT_DICT_TIMEOUTS: *value = c->n_dict_timeouts; return ONMF_OK;
         case ONMF_CNT_FALLBACK_SOLVES: *value = c->n_fallback_solves; return ONMF_OK;
+        case ONMF_CNT_DEVICE_RESOLVES: *value = c->n_device_resolves; return ONMF_OK;
         default: return onmf_fail(c, ONMF_ERR_ARG, "onmf_get_counter: unknown counter %d", which);
     }
 }
@@ -411,6 +413,7 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
         const bool refresh_probes = c->screen_refresh_due || probes_new;
         double min_margin = 1e300;       // smallest (lower bound / tol) among the "continue" verdicts
         bool undecided = false, posted = false, chain_clean = true;   // chain = one enqueue of sweeps + verdicts
+        bool resolved_on_device = false;
         if (c->cu_count == 0) {
             int cus = 0;
             HIP_TRY(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
@@ -452,14 +455,32 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
             // (the first enqueue of a solve does not run ahead when the previous solve needed the host:
             // chances are this one does too, and the work enqueued here would run twice; once the host
             // has settled a sweep, what follows is short and usually conclusive, so it does again)
-            const bool ahead = after && (rb & 3) == 0 && (start > 0 || !c->screen_last_undecided);
+            // Small r, where borderline tests are frequent and a step is short (opt-in,
+            // ONMF_OPT_DEVICE_RESOLVE): when the previous solve needed a full evaluation, one round of
+            // device-side resolution is enqueued behind the launch (settle the first inconclusive verdict
+            // in place, go on sweeping from there) before the host looks at anything.  It costs three
+            // near-empty launches when it turns out not to be needed.
+            const int dev_rounds = (start == 0 && persistent && c->device_resolve && screen_resolve_covers(r) &&
+                                    c->screen_last_undecided) ? 1 : 0;
+            const bool ahead = after && (rb & 3) == 0 && (start > 0 || !c->screen_last_undecided || dev_rounds > 0);
             posted = false;
             if (ahead && behind_sweeps) ONMF_TRY((*behind_sweeps)());
             // a sweep evaluates the test of the one two sweeps back: the last two are still open
             ONMF_TRY(launch_screen_final(c, base, std::max(start, sub_iter - 2), sub_iter - 1, (float)tol,
                                          (float)rank_cap, s));
+            for (int rd = 0; rd < dev_rounds; ++rd) {
+                const int* next = reinterpret_cast<const int*>(base) + ScreenLayout::NEXT;
+                ONMF_TRY(launch_screen_resolve(c, base, r, b, buf, sub_iter, (float)tol, s));
+                const ScreenDev sc2 = {base, 0, (float)tol, (float)rank_cap, sc.spin_limit, next, sub_iter};
+                int groups = 0;
+                ONMF_TRY(profile_mark(c, s));
+                ONMF_TRY(launch_sweep(c, r, b, Gm, Cm, buf, alpha, 0, 0, sub_iter, (double*)c->stats.p, &groups, s, &sc2));
+                ONMF_TRY(profile_mark(c, s));
+                ONMF_TRY(launch_screen_final(c, base, 0, sub_iter - 1, (float)tol, (float)rank_cap, s, next));
+            }
+            // (the records, and behind them the resolution's own words: NEXT, NRES)
             HIP_TRY(c, hipMemcpyAsync(c->pinned, base + ScreenLayout::REC,
-                                      (size_t)4 * SCREEN_MAX_SWEEPS * sizeof(float), hipMemcpyDeviceToHost, s));
+                                      (size_t)(4 * SCREEN_MAX_SWEEPS + 4) * sizeof(float), hipMemcpyDeviceToHost, s));
             if (ahead) {
                 // the host waits for the records only; the follow-up work is already behind them
                 if (!c->ev_rec) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_rec, hipEventDisableTiming));
@@ -472,6 +493,13 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
                 HIP_TRY(c, hipStreamSynchronize(s));
             }
             const float* rec = (const float*)c->pinned;
+            if (dev_rounds > 0) {
+                const int nres = reinterpret_cast<const int*>(rec)[4 * SCREEN_MAX_SWEEPS + 1];
+                if (nres > 0) {
+                    c->n_device_resolves += nres;
+                    resolved_on_device = true;
+                }
+            }
             int next_start = sub_iter;
             bool stop = false;
             chain_clean = true;
@@ -542,8 +570,8 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
             start = next_start;
         }
         // the next solve refreshes its probes if these left the bounds undecided or close to it
-        c->screen_refresh_due = undecided || min_margin < 1.5;
-        c->screen_last_undecided = undecided;
+        c->screen_refresh_due = undecided || resolved_on_device || min_margin < 1.5;
+        c->screen_last_undecided = undecided || resolved_on_device;
         if (posted && chain_clean) {     // the device put the result in H and the follow-up work stands
             if (after_valid) *after_valid = true;
             if (sweeps_done) *sweeps_done = done;

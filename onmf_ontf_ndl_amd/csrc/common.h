@@ -46,6 +46,9 @@ struct onmf_ctx {
     int ev_used = 0;
     DevBuf dbuf;                    // H - H_prev for the exact stopping test (r x b)
     DevBuf gstack;                  // small r: [H - H_prev ; H_prev] stacked (2r x b), one product for both Grams
+    DevBuf rslab;                   // device-side verdict resolution: per-workgroup partial Gram matrices
+    int device_resolve = 0;         // settle inconclusive verdicts on the device (r <= 64; opt-in: see screen.hip)
+    long long n_device_resolves = 0;
     DevBuf screen;                  // stopping-test screen state (ScreenLayout)
     DevBuf slab_side;               // split-K slabs of products issued on the side stream
     hipStream_t side = nullptr;     // dictionary pass runs here, beside the code solve
@@ -160,6 +163,8 @@ struct ScreenDev {
     float tol;           // stopping_diff
     float rank_cap;      // min(r, b)
     long long spin_limit;    // bound (100 MHz ticks) on waiting for the other workgroups' sums
+    const int* start_dev;    // not null: the launch's first sweep is read from here (and is its v_first), ...
+    int k_end;               // ... its last sweep is k_end - 1
 };
 
 // Per-column stopping (many independent one-column solves in one launch).
@@ -230,7 +235,11 @@ struct ScreenLayout {           // offsets in floats into ctx->screen
     static constexpr int FLAG = UBH + SCREEN_MAX_SWEEPS + 1;       // int: 0 = keep sweeping
     static constexpr int AVEC = FLAG + 1;          // 16: last Ritz coefficient vector (warm start)
     static constexpr int REC = AVEC + 16;          // SCREEN_MAX_SWEEPS x 4 floats
-    static constexpr int CWY = REC + 4 * SCREEN_MAX_SWEEPS;        // 256 doubles: H H^T v
+    // device-side resolution of an inconclusive verdict (screen_resolve_kernel): ints
+    static constexpr int NEXT = REC + 4 * SCREEN_MAX_SWEEPS;       // first sweep of the launch enqueued behind it
+    static constexpr int NRES = NEXT + 1;                          // verdicts resolved on the device in this solve
+    static constexpr int RCNT = NEXT + 2;                          // its workgroups done with their partial Grams
+    static constexpr int CWY = NEXT + 4;                           // 256 doubles: H H^T v
     static constexpr int TOTAL = CWY + 512;
 };
 static_assert(ScreenLayout::SETS % 2 == 0 && ScreenLayout::SETSZ % 2 == 0 && ScreenLayout::SET_SUMS % 2 == 0 &&
@@ -333,8 +342,15 @@ __device__ __forceinline__ int screen_eval_wave(float* base, int j, float& ub, f
 
 int launch_screen_init(onmf_ctx* c, float* base, int r, hipStream_t s);
 // the verdicts that no sweep of the launch evaluated: sweeps k_from .. k_last, in order
+// (start_dev not null: k_from = max(*start_dev, k_last - 1), nothing if *start_dev > k_last)
 int launch_screen_final(onmf_ctx* c, float* base, int k_from, int k_last, float tol, float rank_cap,
-                        hipStream_t s);
+                        hipStream_t s, const int* start_dev = nullptr);
+// r <= 64: settle the first inconclusive verdict in the records on the device - both Gram matrices, their
+// top eigenvalues, the reference's comparison - and prepare the launch enqueued behind it (first sweep in
+// ScreenLayout::NEXT, flag and accumulator sets reopened).  Does nothing if there is none to settle.
+int launch_screen_resolve(onmf_ctx* c, float* base, int r, int b, float* const* hb, int sub_iter, float tol,
+                          hipStream_t s);
+bool screen_resolve_covers(int r);
 // reopen the loop after the host settled sweep k - 1: flag = 0; ub = an upper bound of
 // sigma_max(H before sweep k) if the host knows one, else -1
 int launch_screen_clear_flag(onmf_ctx* c, float* base, int k, hipStream_t s, float ub = -1.0f);

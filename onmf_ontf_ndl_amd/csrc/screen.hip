@@ -16,6 +16,8 @@
 // the top Ritz direction placed in probe 0 and the other probes kept orthogonal to it.
 #include "common.h"
 
+#include <algorithm>
+
 namespace {
 
 __device__ __forceinline__ int swz(int row) { return (-(row >> 2)) & 3; }
@@ -150,8 +152,15 @@ int run_refresh(onmf_ctx* c, int r, int b, const float* Hnew, const float* Hold,
 // The verdicts that no sweep evaluated (a sweep evaluates the one two sweeps back): sweeps
 // k_from .. k_last in order, up to the first that ends the loop (one wave).
 __global__ __launch_bounds__(64) void screen_final_kernel(float* base, int k_from, int k_last, float tol,
-                                                          float rank_cap) {
+                                                          float rank_cap, const int* start_dev) {
     if (reinterpret_cast<const int*>(base)[ScreenLayout::FLAG] != 0) return;   // the loop ended earlier (uniform)
+    if (start_dev != nullptr) {
+        // behind a launch whose first sweep came from device memory: that launch evaluated the tests from
+        // its first sweep up to two before its last
+        const int first = *start_dev;
+        if (first > k_last) return;
+        k_from = max(first, k_last - 1);
+    }
     float ub = base[ScreenLayout::UBH + k_from];
     for (int j = k_from; j <= k_last; ++j)
         if (screen_eval_wave(base, j, ub, tol, rank_cap, true) != 0) break;
@@ -364,6 +373,261 @@ __global__ __launch_bounds__(256) void screen_cw_finish_kernel(int r, float* bas
     if (tid == 0 && lam > 0.f && lam < 3.0e38f) base[ScreenLayout::UBH + k] = sqrtf(lam * (1.0f + 1e-4f)) * (1.0f + 1e-6f);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Device-side resolution of an inconclusive verdict (r <= 64).
+//
+// Where the bounds straddle stopping_diff the test has to be evaluated in full:
+//     dist = sqrt(lambda_max(D D^T) / lambda_max(H H^T)),  D = H_new - H_old, H = H_old   (src/onmf.py:265)
+// The host can do that (api.hip: exact_dist), at the price of two round trips through the launch queue
+// and the PCIe bus per event; for small r - where a step is a few hundred microseconds and the small
+// Gram matrices make borderline tests frequent - this kernel does it in place, enqueued ahead of time
+// behind a one-launch solve and followed by another launch of the sweep kernel that takes its first
+// sweep from device memory:
+//   1. every workgroup finds the sweep i to settle in the verdict records (the first inconclusive one
+//      with only "continue" before it; none: nothing to do), reads its columns of H_new (ring buffer
+//      (i+1) % 3) and H_old (i % 3), stages D and H_old transposed in LDS and accumulates its part of the
+//      two RP x RP Gram matrices on the matrix cores (contraction over columns: the transposed tile puts
+//      the column index on the MFMA's k lanes, and one fragment serves as both operands);
+//   2. the parts go to a slab per workgroup; the workgroup that finishes last adds them in workgroup
+//      order (bitwise reproducible) into LDS, in double;
+//   3. two of its waves find the top eigenvalues by power iteration in double (Rayleigh quotients of
+//      a positive semi-definite matrix only grow; the iteration ends when they have stopped moving; the
+//      second eigenvalue of these matrices is 3-10 % of the first for H H^T and up to 3/4 for D D^T, i.e.
+//      5 to 60 steps of 64 multiply-adds per lane), one lane makes the reference's comparison and
+//      writes the verdict; for "continue" it reopens the loop exactly as the host would
+//      (screen_clear_flag_kernel): accumulator sets and counts of the next two sweeps cleared, the exact
+//      sigma_max(H_old) + sigma_max(D) as the next sweep's bound, flag 0, NEXT = i + 1.
+// An iteration that has not settled after RESOLVE_MAX_STEPS steps (a flat spectrum) leaves the record
+// as it is: the host then does it.
+// Measured (MI355X, c2 shape d=1024 r=64 b=8192): the kernel takes 79 us (13 power steps for D D^T) and a
+// step 0.47 ms with it against 0.44 ms with the host in the loop (whose part is about 125 us but overlaps
+// less badly than it looks under a profiler); at r = 16-25 the moves' Gram matrix has a flat spectrum
+// (second eigenvalue 0.7 of the first), the iteration needs 200-600 steps and a step gets slower (c1: 0.55
+// against 0.33 ms).  It is therefore OFF by default (ONMF_OPT_DEVICE_RESOLVE); what it needs to pay is a
+// Lanczos iteration in place of the power iteration and a Gram phase spread over more workgroups.
+// ---------------------------------------------------------------------------------------------
+constexpr int RESOLVE_MAX_STEPS = 200;
+constexpr int RESOLVE_COLS = 64;        // columns per staged tile
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+template <int NB>
+__global__ __launch_bounds__(256) void screen_resolve_kernel(float* base, int r, int b, const float* hb0,
+                                                             const float* hb1, const float* hb2, int sub_iter,
+                                                             float tol, float* slab, int cols_per_wg) {
+    constexpr int RP = 16 * NB;
+    constexpr int PITCH = RP + 4;                       // staged tiles are [column][row], rows padded
+    constexpr int NPAIR = NB * NB;                      // 16 x 16 output blocks of one Gram matrix
+    constexpr int PER_WAVE = (NPAIR + 3) / 4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* Dt = lds;                                    // [RESOLVE_COLS][PITCH]
+    float* Ht = lds + RESOLVE_COLS * PITCH;
+    __shared__ int sel_s, last_s;
+    __shared__ double lam_s[2];
+    __shared__ int ok_s[2];
+    int* ibase = reinterpret_cast<int*>(base);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c16 = lane & 15, g4 = lane >> 4;
+    if (tid == 0) {
+        int sel = -1;
+        if (ibase[ScreenLayout::FLAG] != 0) {           // the loop was ended: by a stop, or for want of a verdict
+            for (int i = 0; i < sub_iter; ++i) {
+                const int code = (int)base[ScreenLayout::REC + 4 * i + 2];
+                if (code == 1) continue;
+                if (code == 3 && i + 1 < sub_iter) sel = i;   // (the last sweep's test decides nothing)
+                break;
+            }
+        }
+        sel_s = sel;
+    }
+    __syncthreads();
+    const int isel = sel_s;
+    if (isel < 0) {
+        if (blockIdx.x == 0 && tid == 0) ibase[ScreenLayout::NEXT] = sub_iter;    // nothing follows
+        return;
+    }
+    const float* Hnew = ((isel + 1) % 3 == 0) ? hb0 : ((isel + 1) % 3 == 1) ? hb1 : hb2;
+    const float* Hold = (isel % 3 == 0) ? hb0 : (isel % 3 == 1) ? hb1 : hb2;
+
+    // ---- 1. this workgroup's part of the two Gram matrices ----
+    f32x4 accD[PER_WAVE], accH[PER_WAVE];
+#pragma unroll
+    for (int p = 0; p < PER_WAVE; ++p) accD[p] = accH[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int col_lo = blockIdx.x * cols_per_wg, col_hi = min(b, col_lo + cols_per_wg);
+    for (int c0 = col_lo; c0 < col_hi; c0 += RESOLVE_COLS) {
+        __syncthreads();                                // the previous tile's readers are done
+        for (int e = tid; e < RP * RESOLVE_COLS; e += 256) {
+            const int row = e / RESOLVE_COLS, cc = e % RESOLVE_COLS;     // consecutive threads: consecutive columns
+            const int col = c0 + cc;
+            float hn = 0.f, ho = 0.f;
+            if (row < r && col < col_hi) {
+                hn = Hnew[(size_t)row * b + col];
+                ho = Hold[(size_t)row * b + col];
+            }
+            Dt[cc * PITCH + row] = hn - ho;
+            Ht[cc * PITCH + row] = ho;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < PER_WAVE; ++p) {
+            const int pair = wave + 4 * p;
+            if (pair < NPAIR) {                         // wave-uniform
+                const int bi = pair / NB, bj = pair % NB;
+#pragma unroll
+                for (int q = 0; q < RESOLVE_COLS / 4; ++q) {
+                    // fragment of block row bi: lane (m = c16, k = g4) = X[16 bi + m][column 4 q + k]; the
+                    // same layout serves as the B operand of X X^T with n = c16
+                    const int at = (4 * q + g4) * PITCH + c16;
+                    accD[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(Dt[at + 16 * bi], Dt[at + 16 * bj], accD[p], 0, 0, 0);
+                    accH[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ht[at + 16 * bi], Ht[at + 16 * bj], accH[p], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- 2. slab of this workgroup, then the last one adds them all ----
+    float* mine = slab + (size_t)blockIdx.x * 2 * RP * RP;
+#pragma unroll
+    for (int p = 0; p < PER_WAVE; ++p) {
+        const int pair = wave + 4 * p;
+        if (pair < NPAIR) {
+            const int bi = pair / NB, bj = pair % NB;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {               // acc[t] = S[16 bi + 4 g + t][16 bj + c]
+                const int at = (16 * bi + 4 * g4 + t) * RP + 16 * bj + c16;
+                __hip_atomic_store(mine + at, accD[p][t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(mine + RP * RP + at, accH[p][t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) {
+        const int done = __hip_atomic_fetch_add(ibase + ScreenLayout::RCNT, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        last_s = (done == (int)gridDim.x - 1);
+    }
+    __syncthreads();
+    if (!last_s) return;
+    __threadfence();
+    // (the staging tiles are dead: the double-precision matrices take their place)
+    double* S = reinterpret_cast<double*>(lds);         // [2][RP * RP]
+    // (the other workgroups released their slabs before they counted themselves in, and the fence above
+    // is the acquire: ordinary vector loads from here on, many in flight)
+    {
+        constexpr int QUADS = 2 * RP * RP / 4;
+        const float4* slab4 = reinterpret_cast<const float4*>(slab);
+        for (int e = tid; e < QUADS; e += 256) {
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            unsigned w = 0;
+            for (; w + 3 < gridDim.x; w += 4) {
+                const float4 a = slab4[(size_t)(w + 0) * QUADS + e], bq = slab4[(size_t)(w + 1) * QUADS + e];
+                const float4 cq = slab4[(size_t)(w + 2) * QUADS + e], dq = slab4[(size_t)(w + 3) * QUADS + e];
+                s0 += (double)a.x; s1 += (double)a.y; s2 += (double)a.z; s3 += (double)a.w;
+                s0 += (double)bq.x; s1 += (double)bq.y; s2 += (double)bq.z; s3 += (double)bq.w;
+                s0 += (double)cq.x; s1 += (double)cq.y; s2 += (double)cq.z; s3 += (double)cq.w;
+                s0 += (double)dq.x; s1 += (double)dq.y; s2 += (double)dq.z; s3 += (double)dq.w;
+            }
+            for (; w < gridDim.x; ++w) {
+                const float4 a = slab4[(size_t)w * QUADS + e];
+                s0 += (double)a.x; s1 += (double)a.y; s2 += (double)a.z; s3 += (double)a.w;
+            }
+            S[4 * e] = s0; S[4 * e + 1] = s1; S[4 * e + 2] = s2; S[4 * e + 3] = s3;
+        }
+    }
+    __syncthreads();
+    // ---- 3. top eigenvalues: wave 0 of D D^T, wave 1 of H H^T ----
+    if (wave < 2) {
+        const double* M = S + wave * RP * RP;
+        double* vb = S + 2 * RP * RP + wave * 64;       // this wave's copy of the iterate
+        const bool act = lane < RP;
+        double v = act ? 1.0 + 0.5 * sin(12.9898 * (double)(lane + 1)) : 0.0;
+        double nv = wave_sum_f64(v * v);
+        v *= 1.0 / sqrt(nv);
+        double theta = 0.0, prev = -1.0;
+        int calm = 0, ok = 0;
+        for (int it = 0; it < RESOLVE_MAX_STEPS; ++it) {
+            vb[lane] = v;
+            __builtin_amdgcn_wave_barrier();
+            double y = 0.0;
+            if (act) {
+#pragma unroll 8
+                for (int j = 0; j < RP; ++j) y = fma(M[j * RP + lane], vb[j], y);    // M symmetric: column = row
+            }
+            __builtin_amdgcn_wave_barrier();
+            theta = wave_sum_f64(v * y);                // Rayleigh quotient of the unit vector v
+            const double ny = wave_sum_f64(y * y);
+            if (!(ny > 0.0)) { ok = (ny == 0.0); theta = 0.0; break; }     // zero matrix (or NaN: not ok)
+            v = y * (1.0 / sqrt(ny));
+            if (prev >= 0.0 && theta - prev <= 1e-15 * theta) {
+                if (++calm >= 2) { ok = 1; break; }
+            } else {
+                calm = 0;
+            }
+            prev = theta;
+        }
+        if (lane == 0) {
+            lam_s[wave] = theta;
+            ok_s[wave] = ok;
+        }
+    }
+    __syncthreads();
+    const double lD = lam_s[0], lH = lam_s[1];
+    const bool settled = ok_s[0] && ok_s[1] && lH > 0.0 && lD >= 0.0;     // else: left to the host
+    const double dist = settled ? sqrt(lD) / sqrt(lH) : 0.0;
+    const bool keep = dist > (double)tol;               // the loop test of src/onmf.py:252
+    if (settled && keep) {
+        // reopen the loop at sweep isel + 1 (the stopped launch had already run it once ahead of this verdict)
+        for (int j = isel + 1; j < SCREEN_MAX_SWEEPS && j < isel + 3; ++j) {
+            for (int e = tid; e < ScreenLayout::SETSZ; e += 256) base[ScreenLayout::SETS + j * ScreenLayout::SETSZ + e] = 0.f;
+            if (tid == 0) ibase[ScreenLayout::CNT + j] = 0;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        ibase[ScreenLayout::RCNT] = 0;
+        if (settled) {
+            float* rec = base + ScreenLayout::REC + 4 * isel;
+            rec[0] = (float)dist;
+            rec[1] = (float)dist;
+            rec[2] = keep ? 1.0f : 2.0f;
+            ibase[ScreenLayout::NRES] += 1;
+            if (keep) {
+                base[ScreenLayout::UBH + isel + 1] = (float)((sqrt(lH) + sqrt(lD)) * (1.0 + 1e-5));
+                ibase[ScreenLayout::NEXT] = isel + 1;
+                __threadfence();
+                ibase[ScreenLayout::FLAG] = 0;
+            } else {
+                ibase[ScreenLayout::NEXT] = sub_iter;
+            }
+        } else {
+            ibase[ScreenLayout::NEXT] = sub_iter;
+        }
+    }
+}
+
+template <int NB>
+int run_resolve(onmf_ctx* c, float* base, int r, int b, float* const* hb, int sub_iter, float tol, hipStream_t s) {
+    constexpr int RP = 16 * NB;
+    // columns per workgroup: at least 256 and a multiple of the tile, at most 64 workgroups
+    int cols = std::max(256, (b + 63) / 64);
+    cols = (cols + RESOLVE_COLS - 1) / RESOLVE_COLS * RESOLVE_COLS;
+    const int nwg = (b + cols - 1) / cols;
+    ONMF_TRY(onmf_reserve(c, c->rslab, (size_t)nwg * 2 * RP * RP * sizeof(float), "verdict resolution slabs"));
+    const size_t tiles = (size_t)2 * RESOLVE_COLS * (RP + 4) * sizeof(float);
+    const size_t mats = ((size_t)2 * RP * RP + 2 * 64) * sizeof(double);
+    const size_t lds = std::max(tiles, mats);
+    static LdsLimit lim;
+    ONMF_TRY(onmf_raise_lds_limit(c, lim, (const void*)screen_resolve_kernel<NB>, lds));
+    hipLaunchKernelGGL((screen_resolve_kernel<NB>), dim3(nwg), dim3(256), lds, s, base, r, b, hb[0], hb[1], hb[2],
+                       sub_iter, tol, (float*)c->rslab.p, cols);
+    HIP_TRY(c, hipGetLastError());
+    return ONMF_OK;
+}
+
 }  // namespace
 
 int launch_screen_cw(onmf_ctx* c, float* base, int r, int b, const float* H, int k, hipStream_t s) {
@@ -383,8 +647,8 @@ int launch_screen_init(onmf_ctx* c, float* base, int r, hipStream_t s) {
 }
 
 int launch_screen_final(onmf_ctx* c, float* base, int k_from, int k_last, float tol, float rank_cap,
-                        hipStream_t s) {
-    hipLaunchKernelGGL(screen_final_kernel, dim3(1), dim3(64), 0, s, base, k_from, k_last, tol, rank_cap);
+                        hipStream_t s, const int* start_dev) {
+    hipLaunchKernelGGL(screen_final_kernel, dim3(1), dim3(64), 0, s, base, k_from, k_last, tol, rank_cap, start_dev);
     HIP_TRY(c, hipGetLastError());
     return ONMF_OK;
 }
@@ -413,6 +677,19 @@ int launch_screen_refresh(onmf_ctx* c, float* base, int r, int b, const float* H
     hipLaunchKernelGGL(screen_probe_update_kernel, dim3(1), dim3(256), 0, s, base, r);
     HIP_TRY(c, hipGetLastError());
     return ONMF_OK;
+}
+
+bool screen_resolve_covers(int r) { return r >= 1 && r <= 64; }
+
+int launch_screen_resolve(onmf_ctx* c, float* base, int r, int b, float* const* hb, int sub_iter, float tol,
+                          hipStream_t s) {
+    switch ((r + 15) / 16) {
+        case 1: return run_resolve<1>(c, base, r, b, hb, sub_iter, tol, s);
+        case 2: return run_resolve<2>(c, base, r, b, hb, sub_iter, tol, s);
+        case 3: return run_resolve<3>(c, base, r, b, hb, sub_iter, tol, s);
+        case 4: return run_resolve<4>(c, base, r, b, hb, sub_iter, tol, s);
+    }
+    return onmf_fail(c, ONMF_ERR_ARG, "verdict resolution on the device covers r <= 64 (r=%d)", r);
 }
 
 int launch_screen_clear_flag(onmf_ctx* c, float* base, int k, hipStream_t s, float ub) {

@@ -84,7 +84,7 @@ __device__ __forceinline__ float row_sum16(float x) {
 template <int NB, bool HALF, bool PROBE, int CT, bool EACH = false, int WPG = 16 / CT>
 __global__ __launch_bounds__(64 * WPG) void sweep_tile_kernel(
     int r, int b, const float* __restrict__ Gm, const float* __restrict__ Cm, float* hb0, float* hb1,
-    float* hb2, float alpha, int exact_cd, int k_first, int k_count, double* __restrict__ stats,
+    float* hb2, float alpha, int exact_cd, int k_first_arg, int k_count_arg, double* __restrict__ stats,
     ScreenDev sc, EachStop es) {
     static_assert(!EACH || (!PROBE && CT == 1), "per-column stopping: plain kernel, one tile per wave");
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -100,9 +100,18 @@ __global__ __launch_bounds__(64 * WPG) void sweep_tile_kernel(
     int* verdict_s = reinterpret_cast<int*>(p2wg + 20);     // PROBE: verdict handed from wave 0 to the rest
 
     const int tid = threadIdx.x;
+    int k_first = k_first_arg, k_count = k_count_arg, v_first = sc.v_first;
     if (PROBE) {
         // an earlier launch's test ended the loop (grid-uniform)
         if (reinterpret_cast<const int*>(sc.base)[ScreenLayout::FLAG] != 0) return;
+        if (sc.start_dev != nullptr) {
+            // enqueued before its first sweep was known (behind a device-side resolution of an
+            // inconclusive verdict): it is in device memory
+            k_first = *sc.start_dev;
+            k_count = sc.k_end - k_first;
+            v_first = k_first;
+            if (k_count <= 0) return;
+        }
     }
 
     const int lane = tid & 63;
@@ -197,7 +206,7 @@ __global__ __launch_bounds__(64 * WPG) void sweep_tile_kernel(
 #pragma unroll
         for (int t = 0; t < 4; ++t)
             cmn[ct][t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_c, voff[ct], t * b * 4, 0));
-    float ub = PROBE ? sc.base[ScreenLayout::UBH + sc.v_first] : -1.0f;    // bound carried by wave 0
+    float ub = PROBE ? sc.base[ScreenLayout::UBH + v_first] : -1.0f;       // bound carried by wave 0
     bool active = true;                    // EACH: this lane's column is still iterating
     int col_sweeps = 0;
 
@@ -207,7 +216,7 @@ __global__ __launch_bounds__(64 * WPG) void sweep_tile_kernel(
             if (wave == 0) {
                 int verdict = 0;
                 const int j = k - 2;
-                if (j >= sc.v_first) {
+                if (j >= v_first) {
                     const int* cnt = reinterpret_cast<const int*>(sc.base) + ScreenLayout::CNT + j;
                     // (requested together with the first look at the count; 0 = none, as negative)
                     const float seeded = fmaxf(sc.base[ScreenLayout::UBH + j + 1], 0.f);

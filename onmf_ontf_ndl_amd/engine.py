@@ -96,7 +96,8 @@ class Engine:
         workgroups gave up waiting for each other, and solves that ran one launch per sweep since."""
         out = {}
         for name, key in (("sweep_timeouts", _lib.CNT_SWEEP_TIMEOUTS), ("dict_timeouts", _lib.CNT_DICT_TIMEOUTS),
-                          ("fallback_solves", _lib.CNT_FALLBACK_SOLVES)):
+                          ("fallback_solves", _lib.CNT_FALLBACK_SOLVES),
+                          ("device_resolves", _lib.CNT_DEVICE_RESOLVES)):
             v = C.c_longlong(0)
             _lib.check(self.lib.onmf_get_counter(self.ctx, key, C.byref(v)), self.ctx, "onmf_get_counter")
             out[name] = int(v.value)

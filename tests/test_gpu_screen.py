@@ -188,3 +188,53 @@ def test_a_timed_out_one_launch_solve_is_redone_launch_by_launch(eng):
     _, launches = eng.get_profile()
     eng.set_option(1, 0)
     assert torch.equal(third[0], ref[0]) and launches <= 2
+
+
+@pytest.mark.parametrize("d,r,b", [(64, 16, 500), (200, 64, 3000), (128, 40, 1111), (100, 25, 1000)])
+def test_inconclusive_verdicts_are_settled_on_the_device_for_small_r(eng, d, r, b):
+    """r <= 64, ONMF_OPT_DEVICE_RESOLVE on: once a solve has needed a full evaluation of the stopping test, the next one carries a round
+    of device-side resolution (Gram matrices, eigenvalues and the comparison on the GPU, the sweeps
+    continued from there).  Thresholds are placed right next to the exact dist of a middle sweep - just
+    below (the loop must go on) and just above (it must end there) - so that the bounds cannot decide.
+    Sweep counts and codes must equal those of the path that evaluates every test in full on the host."""
+    import torch
+    g = torch.Generator(device=eng.device).manual_seed(7 * d + r)
+    X = torch.rand(d, b, device=eng.device, generator=g)
+    W = torch.rand(d, r, device=eng.device, generator=g)
+    W = W / torch.clamp(torch.linalg.norm(W, dim=0), min=1.0)
+    H0 = torch.rand(r, b, device=eng.device, generator=g)
+    eng.set_option(EXACT, 1)
+    _, _, de = eng.sparse_code(X, W, H0=H0, sub_iter=12, stopping_diff=0.0)
+    eng.set_option(EXACT, 0)
+    assert len(de) == 12
+    eng.set_option(9, 1)                          # device-side resolution is opt-in
+    for k in (3, 6, 9):
+        for tol in (float(min(de[:k + 1]) * 0.995), float(de[k] * 1.005)):
+            eng.set_option(EXACT, 1)
+            He, se, _ = eng.sparse_code(X, W, H0=H0, sub_iter=12, stopping_diff=tol)
+            eng.set_option(EXACT, 0)
+            before = eng.counters()["device_resolves"]
+            first = eng.sparse_code(X, W, H0=H0, sub_iter=12, stopping_diff=tol)     # host settles (and arms the device round)
+            second = eng.sparse_code(X, W, H0=H0, sub_iter=12, stopping_diff=tol)
+            third = eng.sparse_code(X, W, H0=H0, sub_iter=12, stopping_diff=tol)
+            for out in (first, second, third):
+                assert out[1] == se, (k, tol)
+                assert torch.equal(out[0], He), (k, tol)
+            # the settled sweep's value in the trace is the exact dist, as the host path reports it
+            if se - 1 < len(de):
+                np.testing.assert_allclose(third[2][se - 1], de[se - 1], rtol=1e-4)
+            assert eng.counters()["device_resolves"] >= before + 1, (k, tol)
+    # switched off (the default): same results, nothing settled on the device
+    eng.set_option(9, 0)
+    try:
+        before = eng.counters()["device_resolves"]
+        tol = float(de[6] * 1.005)
+        eng.set_option(EXACT, 1)
+        He, se, _ = eng.sparse_code(X, W, H0=H0, sub_iter=12, stopping_diff=tol)
+        eng.set_option(EXACT, 0)
+        for _ in range(2):
+            Hs, ss, _ = eng.sparse_code(X, W, H0=H0, sub_iter=12, stopping_diff=tol)
+            assert ss == se and torch.equal(Hs, He)
+        assert eng.counters()["device_resolves"] == before
+    finally:
+        eng.set_option(9, 0)
