@@ -18,6 +18,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <type_traits>
 
 namespace {
 
@@ -116,6 +117,24 @@ __device__ __forceinline__ void store_tile(float* __restrict__ S, const float4 (
     }
 }
 
+// One quarter (part p) of store_tile.
+template <bool KMAJ>
+__device__ __forceinline__ void store_part(float* __restrict__ S, const float4& v, int p) {
+    const int t = threadIdx.x;
+    if (KMAJ) {
+        const int k = (t & 7) + 8 * p;
+        const int x = (t >> 3) * 4;
+        S[lds_off(x + 0, k)] = v.x;
+        S[lds_off(x + 1, k)] = v.y;
+        S[lds_off(x + 2, k)] = v.z;
+        S[lds_off(x + 3, k)] = v.w;
+    } else {
+        const int x = (t >> 3) + 32 * p;
+        const int k = (t & 7) * 4;
+        *reinterpret_cast<float4*>(S + lds_off(x, k)) = v;
+    }
+}
+
 // Tile source.  Interior tiles of aligned operands come through a buffer descriptor: the per-thread
 // byte offsets are computed once, the tile origin is a scalar offset, so a tile costs no vector
 // arithmetic at all (vector ALU cycles are not hidden behind fp32 MFMAs on this chip).  Edge tiles
@@ -147,10 +166,13 @@ struct TileSource {
     }
     // NT: non-temporal loads - for an operand that is streamed (each element read by one or two
     // workgroups), so that it does not push the small matrices other kernels work on out of the L2
-    template <bool NT = false>
+    // SURE: the caller has checked that this source is `fast` and the tile a whole one: no branch at all,
+    // so that the compiler can count the loads in flight (behind a branch it falls back to waiting for
+    // ALL of them wherever it needs one, which turns a prefetch two tiles ahead into half a tile)
+    template <bool NT = false, bool SURE = false>
     __device__ __forceinline__ void load(int tile, float4 (&rg)[4]) const {
         const int k0 = kbeg + tile * BK;
-        if (fast && k0 + BK <= kend) {                       // uniform
+        if (SURE || (fast && k0 + BK <= kend)) {             // uniform
             const unsigned so = soff0 + (unsigned)tile * sstep;
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
@@ -161,6 +183,12 @@ struct TileSource {
         } else {
             load_tile<KMAJ>(P, ld, xdim, x0, k0, kend, vec_ok, rg);
         }
+    }
+    // one quarter of a whole tile of a `fast` source
+    template <bool NT>
+    __device__ __forceinline__ void load_part(int tile, int p, float4& v) const {
+        const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rs, voff[p], soff0 + (unsigned)tile * sstep, NT ? 2 : 0);
+        v = make_float4(__uint_as_float(u[0]), __uint_as_float(u[1]), __uint_as_float(u[2]), __uint_as_float(u[3]));
     }
 };
 
@@ -207,57 +235,111 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmParams p) {
     srcA.init(p.A, p.lda, p.M, p.K, m0, kbeg, kend, p.vecA);
     if (p.n1 > 0 && n0 >= p.n1) srcB.init(p.B2, p.ldb2, p.N - p.n1, p.K, n0 - p.n1, kbeg, kend, p.vecB2);
     else srcB.init(p.B, p.ldb, p.n1 > 0 ? p.n1 : p.N, p.K, n0, kbeg, kend, p.vecB);
-    if (ntiles > 0) {
-        srcA.load(0, ra);
-        srcB.template load<true>(0, rb);
-        store_tile<A_KM>(As, ra);
-        store_tile<B_KN>(Bs, rb);
-        if (ntiles > 1) {
-            srcA.load(1, ra);
-            srcB.template load<true>(1, rb);
-        }
-    }
-    __syncthreads();
+    // interior workgroup of aligned operands over whole k-tiles: the branch-free loads (uniform)
+    const bool sure = srcA.fast && srcB.fast && ((kend - kbeg) % BK) == 0 && ntiles > 0;
 
-    // one round: MFMAs of tile t; (xa, xb) hold tile t+1, (ya, yb) receive tile t+2
-    auto round = [&](int t, float4 (&xa)[4], float4 (&xb)[4], float4 (&ya)[4], float4 (&yb)[4]) {
-        const int cur = t & 1;
-        if (t + 2 < ntiles) {
-            srcA.load(t + 2, ya);
-            srcB.template load<true>(t + 2, yb);
-        }
-        const float* Ac = As + cur * A_STRIDE;
-        const float* Bc = Bs + cur * B_STRIDE;
-#pragma unroll
-        for (int q = 0; q < BK / 8; ++q) {
-            if (q == BK / 16 && t + 1 < ntiles) {
-                store_tile<A_KM>(As + (cur ^ 1) * A_STRIDE, xa);
-                store_tile<B_KN>(Bs + (cur ^ 1) * B_STRIDE, xb);
-            }
-            const int k = 8 * q + 4 * lhi;
-            const float4 a0 = *reinterpret_cast<const float4*>(Ac + lds_off(wm + l31, k));
-            const float4 a1 = *reinterpret_cast<const float4*>(Ac + lds_off(wm + 32 + l31, k));
-            const float4 b0 = *reinterpret_cast<const float4*>(Bc + lds_off(wn + l31, k));
-            const float4 b1 = *reinterpret_cast<const float4*>(Bc + lds_off(wn + 32 + l31, k));
-            const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
-            const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[j], bv0[j], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[j], bv1[j], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[j], bv0[j], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[j], bv1[j], acc[1][1], 0, 0, 0);
+    auto pipeline = [&](auto sure_c) {
+        constexpr bool SURE = decltype(sure_c)::value;
+        if (SURE) {
+            // tiles 0 and 1 travel together; the loop is entered with no load in flight (a load still
+            // pending at the loop's entry makes the compiler wait at the loop's top on EVERY trip, for
+            // registers it reuses there - which would cut the prefetch distance to half a tile again)
+            srcA.template load<false, true>(0, ra2);
+            srcB.template load<true, true>(0, rb2);
+            srcA.template load<false, true>(min(1, ntiles - 1), ra);
+            srcB.template load<true, true>(min(1, ntiles - 1), rb);
+            store_tile<A_KM>(As, ra2);
+            store_tile<B_KN>(Bs, rb2);
+            __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0)
+        } else if (ntiles > 0) {
+            srcA.template load<false, false>(0, ra);
+            srcB.template load<true, false>(0, rb);
+            store_tile<A_KM>(As, ra);
+            store_tile<B_KN>(Bs, rb);
+            if (ntiles > 1) {
+                srcA.template load<false, false>(1, ra);
+                srcB.template load<true, false>(1, rb);
             }
         }
         __syncthreads();
+
+        // one round: MFMAs of tile t; (xa, xb) hold tile t+1, (ya, yb) receive tile t+2
+        auto round = [&](int t, float4 (&xa)[4], float4 (&xb)[4], float4 (&ya)[4], float4 (&yb)[4]) {
+            const int cur = t & 1;
+            // past the end: the last tile again (never used) rather than a branch around the loads
+            const int tl = min(t + 2, ntiles - 1);
+            if (!SURE && t + 2 < ntiles) {
+                srcA.template load<false, false>(t + 2, ya);
+                srcB.template load<true, false>(t + 2, yb);
+            }
+            const float* Ac = As + cur * A_STRIDE;
+            const float* Bc = Bs + cur * B_STRIDE;
+            float* An = As + (cur ^ 1) * A_STRIDE;
+            float* Bn = Bs + (cur ^ 1) * B_STRIDE;
+            // operands of step q + 1 are read while the MFMAs of step q run (left to itself the compiler
+            // reads them after the MFMAs and waits: an LDS round trip with an idle matrix pipe per step)
+            auto fetch = [&](int q, float4& a0, float4& a1, float4& b0, float4& b1) {
+                const int k = 8 * q + 4 * lhi;
+                a0 = *reinterpret_cast<const float4*>(Ac + lds_off(wm + l31, k));
+                a1 = *reinterpret_cast<const float4*>(Ac + lds_off(wm + 32 + l31, k));
+                b0 = *reinterpret_cast<const float4*>(Bc + lds_off(wn + l31, k));
+                b1 = *reinterpret_cast<const float4*>(Bc + lds_off(wn + 32 + l31, k));
+            };
+            float4 a0, a1, b0, b1, na0, na1, nb0, nb1;
+            fetch(0, a0, a1, b0, b1);
+#pragma unroll
+            for (int q = 0; q < BK / 8; ++q) {
+                if (q + 1 < BK / 8) fetch(q + 1, na0, na1, nb0, nb1);
+                if (!SURE && q == BK / 16 && t + 1 < ntiles) {
+                    store_tile<A_KM>(An, xa);
+                    store_tile<B_KN>(Bn, xb);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
+                const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    // SURE: the tile's 8 loads (step 0) and 8 stores (step 2) go out one at a time, each
+                    // behind a pair of MFMAs - it issues while they run.  Sent as a burst, the memory
+                    // instructions hold the wave's issue slot for longer than the one MFMA in flight
+                    // lasts (measured on this loop: 343 us with bursts, 318 us interleaved, 307 us with
+                    // no memory instructions at all).
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[j], bv0[j], acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[j], bv1[j], acc[0][1], 0, 0, 0);
+                    if (SURE && (q == 0 || q == BK / 16)) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (q == 0) srcA.template load_part<false>(tl, j, ya[j]);
+                        else store_part<A_KM>(An, xa[j], j);     // (last round: a tile nobody reads)
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[j], bv0[j], acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[j], bv1[j], acc[1][1], 0, 0, 0);
+                    if (SURE && (q == 0 || q == BK / 16)) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (q == 0) srcB.template load_part<true>(tl, j, yb[j]);
+                        else store_part<B_KN>(Bn, xb[j], j);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+            }
+            __syncthreads();
+        };
+        // whole pairs of rounds in the loop, an odd last round behind it: a path from the first round of
+        // a trip straight back to the loop's top would carry that round's loads, still in flight, there
+        int t = 0;
+        for (; t + 1 < ntiles; t += 2) {
+            round(t, ra, rb, ra2, rb2);
+            round(t + 1, ra2, rb2, ra, rb);
+            // the accumulators stay in the accumulation registers across the loop edge (left alone, the
+            // compiler carries them through vector registers: 128 copies per trip)
+            asm volatile("" : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[1][0]), "+a"(acc[1][1]));
+        }
+        if (t < ntiles) round(t, ra, rb, ra2, rb2);
     };
-    for (int t = 0; t < ntiles; t += 2) {
-        round(t, ra, rb, ra2, rb2);
-        if (t + 1 < ntiles) round(t + 1, ra2, rb2, ra, rb);
-        // the accumulators stay in the accumulation registers across the loop edge (left alone, the
-        // compiler carries them through vector registers: 128 copies per trip)
-        asm volatile("" : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[1][0]), "+a"(acc[1][1]));
-    }
+    if (sure) pipeline(std::true_type{});
+    else pipeline(std::false_type{});
 
     // accumulator element e of lane l: row (e&3) + 8*(e>>2) + 4*(l>>5), column l&31
     const bool direct = (p.splits == 1);
