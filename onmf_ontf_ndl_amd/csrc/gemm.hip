@@ -27,6 +27,12 @@ constexpr int BN = 128;
 constexpr int BK = 32;
 constexpr int NTHREADS = 256;
 constexpr int TILE_ELEMS = 128 * BK;      // one operand tile in LDS (16 KB)
+// workgroups of a split product, of the chip's 512 slots (two per CU).  510 is faster alone (the aggregate
+// pair: 328 -> 315 us) and slower inside the step (1.616 -> 1.641 ms), where the dictionary pass and the
+// small kernels of the other streams hold slots of their own: workgroups that find none run second.
+#ifndef SPLIT_WG_BUDGET
+#define SPLIT_WG_BUDGET 480
+#endif
 
 // dword offset of element (x, k) of an LDS operand tile
 __device__ __forceinline__ int lds_off(int x, int k) {
@@ -438,7 +444,7 @@ int launch_gemm(onmf_ctx* c, bool a_km, bool b_kn, int M, int N, int K, const fl
         // otherwise a little under two per CU, so that the launch is still ONE round of workgroups when
         // a small kernel on another stream holds a few of the chip's slots (with exactly two per CU a
         // single missing slot leaves one workgroup for a second round: up to twice the time)
-        splits = (tiles <= 4 ? 256 + tiles - 1 : 480) / tiles;
+        splits = (tiles <= 4 ? 256 + tiles - 1 : SPLIT_WG_BUDGET) / tiles;
         const int max_by_k = ktiles / 2;          // at least 2 k-tiles of work per slab
         if (splits > max_by_k) splits = max_by_k;
         if (splits < 1) splits = 1;
@@ -491,7 +497,7 @@ int launch_gemm_pair(onmf_ctx* c, bool a_km, bool b_kn, int M, int K, const floa
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     const int tiles = tiles_m * tiles_n;
     const int ktiles = (K + BK - 1) / BK;
-    int splits = (tiles > 4 && tiles < 256 && ktiles >= 4) ? std::min(480 / tiles, ktiles / 2) : 1;
+    int splits = (tiles > 4 && tiles < 256 && ktiles >= 4) ? std::min(SPLIT_WG_BUDGET / tiles, ktiles / 2) : 1;
     if ((N1 % BN) != 0 || splits < 2 || (beta1 != 0.f && !Cin1) || (beta2 != 0.f && !Cin2)) {
         ONMF_TRY(launch_gemm(c, a_km, b_kn, M, N1, K, A, lda, B1, ldb1, alpha, beta1, Cin1, C1, ldc1, s, slab));
         return launch_gemm(c, a_km, b_kn, M, N2, K, A, lda, B2, ldb2, alpha, beta2, Cin2, C2, ldc2, s, slab);

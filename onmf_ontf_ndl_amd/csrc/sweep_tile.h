@@ -308,39 +308,53 @@ __global__ __launch_bounds__(64 * WPG) void sweep_tile_kernel(
                 for (int t = 0; t < 4; ++t) acc0[ct][t] = alpha_c[ct] - cmn[ct][t];
                 acc1[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            {
-                // the last block fetches block 0 again: the next sweep starts without waiting for it
-                const int Kn = (K + 1 < NB) ? K + 1 : 0;
-    #pragma unroll
-                for (int ct = 0; ct < CT; ++ct)
-    #pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        cmn[ct][t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
-                            rs_c, voff[ct], (16 * Kn + t) * bk * 4, 0));
-            }
-    #pragma unroll
-            for (int J = 0; J < NB; ++J) {
-                // bound how many A-operand reads are in flight at once (register budget)
-                if (NB > 8 && J > 0 && (J % 6) == 0) __builtin_amdgcn_sched_barrier(0);
-                float a0, a1, a2, a3;
+            // The block's memory instructions - the 4 CT loads of the next block's Cm (the last block
+            // fetches block 0 again: the next sweep starts without waiting for it) and the 4 CT stores of
+            // the block before, whose rows are final - go out one at a time between the MFMA groups: each
+            // issues while an MFMA runs.  Sent as bursts they hold the wave's issue slot for longer than
+            // the MFMA in flight lasts.  The A operand of step J + 1 is read before the MFMAs of step J.
+            const int Kn = (K + 1 < NB) ? K + 1 : 0;
+            constexpr int NI = 8 * CT;
+            auto read_a = [&](int J, float (&a)[4]) {
                 if (!HALF || J <= K) {
-                    const float4 a = *reinterpret_cast<const float4*>(
+                    const float4 v = *reinterpret_cast<const float4*>(
                         Gs + blk_index<NB, HALF>(K, J) * 256 + c * 16 + 4 * (g ^ sw_c));
-                    a0 = a.x; a1 = a.y; a2 = a.z; a3 = a.w;
+                    a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w;
                 } else {
                     // Gm[16K+c][16J+4g+t] = Gm[16J+4g+t][16K+c]: rows 4g+t of block (J,K), column c
                     const float* blk = Gs + blk_index<NB, HALF>(J, K) * 256 + 64 * g +
                                        4 * ((c >> 2) ^ ((-g) & 3)) + (c & 3);
-                    a0 = blk[0]; a1 = blk[16]; a2 = blk[32]; a3 = blk[48];
+                    a[0] = blk[0]; a[1] = blk[16]; a[2] = blk[32]; a[3] = blk[48];
                 }
+            };
+            float a_cur[4], a_nxt[4];
+            read_a(0, a_cur);
     #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) acc0[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, h[ct][J][0], acc0[ct], 0, 0, 0);
+            for (int J = 0; J < NB; ++J) {
+                if (J + 1 < NB) read_a(J + 1, a_nxt);
     #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) acc1[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, h[ct][J][1], acc1[ct], 0, 0, 0);
+                for (int i = J * NI / NB; i < (J + 1) * NI / NB; ++i) {
+                    if (i < 4 * CT) {
+                        cmn[i >> 2][i & 3] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                            rs_c, voff[i >> 2], (16 * Kn + (i & 3)) * bk * 4, 0));
+                    } else if (!EACH && K > 0) {
+                        const int ii = i - 4 * CT;
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(h[ii >> 2][K > 0 ? K - 1 : 0][ii & 3]), rs_o,
+                                                              voff[ii >> 2], (16 * (K - 1) + (ii & 3)) * bk * 4, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
     #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) acc0[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, h[ct][J][2], acc0[ct], 0, 0, 0);
+                for (int ct = 0; ct < CT; ++ct) acc0[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[0], h[ct][J][0], acc0[ct], 0, 0, 0);
     #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) acc1[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, h[ct][J][3], acc1[ct], 0, 0, 0);
+                for (int ct = 0; ct < CT; ++ct) acc1[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[1], h[ct][J][1], acc1[ct], 0, 0, 0);
+    #pragma unroll
+                for (int ct = 0; ct < CT; ++ct) acc0[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[2], h[ct][J][2], acc0[ct], 0, 0, 0);
+    #pragma unroll
+                for (int ct = 0; ct < CT; ++ct) acc1[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[3], h[ct][J][3], acc1[ct], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+                for (int t = 0; t < 4; ++t) a_cur[t] = a_nxt[t];
             }
             __builtin_amdgcn_sched_barrier(0);
             // acc = gradient of rows 4g+t of block K (without the in-block corrections)
@@ -416,8 +430,8 @@ __global__ __launch_bounds__(64 * WPG) void sweep_tile_kernel(
             }
             asm volatile("" : "+v"(dsum));     // keep the running sum current (no deferred chain)
             __builtin_amdgcn_s_setprio(0);
-            // rows of block K are final: store them now, under the remaining blocks' arithmetic
-            if (!EACH) {
+            // rows of block K are final: the next block's MFMA loop stores them; the last block's go now
+            if (!EACH && K == NB - 1) {
     #pragma unroll
                 for (int ct = 0; ct < CT; ++ct)
     #pragma unroll
