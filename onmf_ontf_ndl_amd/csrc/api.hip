@@ -14,6 +14,13 @@
 // ---------------------------------------------------------------------------------------------
 static thread_local std::string g_create_error;
 
+// Events that only order this library's own streams on one GPU: nothing on the host ever inspects them, so
+// recording one need not make the GPU's writes visible system-wide (the default for an event).
+#ifndef EV_ORDER_ONLY
+#define EV_ORDER_ONLY (hipEventDisableTiming | hipEventDisableSystemFence)
+#endif
+
+
 int onmf_fail(onmf_ctx* c, int code, const char* fmt, ...) {
     char buf[1024];
     va_list ap;
@@ -335,8 +342,8 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
     if (c->overlap_dict) {
         if (!c->prep) {
             HIP_TRY(c, hipStreamCreateWithFlags(&c->prep, hipStreamNonBlocking));
-            HIP_TRY(c, hipEventCreateWithFlags(&c->ev_prep_fork, hipEventDisableTiming));
-            HIP_TRY(c, hipEventCreateWithFlags(&c->ev_prep_join, hipEventDisableTiming));
+            HIP_TRY(c, hipEventCreateWithFlags(&c->ev_prep_fork, EV_ORDER_ONLY));
+            HIP_TRY(c, hipEventCreateWithFlags(&c->ev_prep_join, EV_ORDER_ONLY));
         }
         ps = c->prep;
         HIP_TRY(c, hipEventRecord(c->ev_prep_fork, s));
@@ -772,8 +779,8 @@ static int step_impl(onmf_ctx* c, int d, int r, int b, const float* X, int ldx, 
         // independent of this step's code and runs on a second stream (default priority) beside it.
         if (!c->side) {
             HIP_TRY(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
-            HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-            HIP_TRY(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+            HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, EV_ORDER_ONLY));
+            HIP_TRY(c, hipEventCreateWithFlags(&c->ev_join, EV_ORDER_ONLY));
         }
         HIP_TRY(c, hipEventRecord(c->ev_fork, s));
         HIP_TRY(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
@@ -791,7 +798,7 @@ static int step_impl(onmf_ctx* c, int d, int r, int b, const float* X, int ldx, 
         const std::function<int()> post_dict = [&]() {
             if (second_posted) return (int)ONMF_OK;
             second_posted = true;
-            if (!c->ev_mid) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_mid, hipEventDisableTiming));
+            if (!c->ev_mid) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_mid, EV_ORDER_ONLY));
             HIP_TRY(c, hipEventRecord(c->ev_mid, s));                 // behind the sweeps
             HIP_TRY(c, hipStreamWaitEvent(c->side, c->ev_mid, 0));
             return launch_dict_pass(c, d, r, W_in, dA, dB, W_out, c->side, 2);
