@@ -585,8 +585,9 @@ int launch_dict_pass(onmf_ctx* c, int d, int r, const float* Win, const float* A
         const int nwg = (d + 1023) / 1024;
         const int lda = (r + 15) / 16 * 16;
         // part 1: atoms before the middle panel boundary, part 2: the rest, part 0: all
-        // (measured at d=1024, r=256: 3/8 - 5/8 leaves the second part longer than the products it runs
-        // beside)
+        // (measured at d=1024, r=256, first part = n/16 of the atoms: 1.59 ms per step for n = 8, 9, 10 and
+        // 1.70 ms for n = 5, 6, 7 - a step, not a slope: with the longer second part the aggregate
+        // product beside it takes 435 us instead of 330 in most steps, one of its workgroups starting late)
         const int jmid = std::max(1, lda / 16 / 2) * 16;
         const int j_begin = part == 2 ? jmid : 0, j_end = part == 1 ? jmid : lda;
         float *Qt, *Ap, *Dt, *Wt, *WtOut;
