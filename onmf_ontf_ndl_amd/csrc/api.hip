@@ -398,7 +398,7 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
         // code, the head of the dictionary pass) take their places on the chip before the product's
         // workgroups fill it - behind them they would wait for its first round to finish.
         init_rc = onmf_reserve(c, c->screen, (size_t)ScreenLayout::TOTAL * sizeof(float), "stop-test screen");
-        if (init_rc == ONMF_OK) init_rc = launch_screen_init(c, (float*)c->screen.p, r, s);
+        if (init_rc == ONMF_OK) init_rc = launch_screen_init(c, (float*)c->screen.p, r, s, sub_iter + 1);
     }
     const int cm_rc = init_rc != ONMF_OK
                           ? init_rc
@@ -421,7 +421,12 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
         // the grid is resident as a whole (one workgroup per CU), else one launch per sweep; they
         // evaluate the stopping test themselves (two sweeps back) and end when it says so.
         float* base = (float*)c->screen.p;
-        const bool refresh_probes = c->screen_refresh_due || probes_new;
+        // Ranks whose sweeps carry the Collatz-Wielandt sums (r <= 128) need no launch boundary for a bound
+        // of sigma_max(H): their probes are refreshed behind the solve, on its LAST move - the late
+        // sweeps are where the test gets close, and the next minibatch's moves resemble this one's sweep
+        // for sweep.  The others cut the first launch after the second sweep for both.
+        const int cw_rows = screen_cw_rows(r);
+        const bool refresh_probes = (c->screen_refresh_due || probes_new) && cw_rows == 0;
         double min_margin = 1e300;       // smallest (lower bound / tol) among the "continue" verdicts
         bool undecided = false, posted = false, chain_clean = true;   // chain = one enqueue of sweeps + verdicts
         bool resolved_on_device = false;
@@ -478,7 +483,7 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
             if (ahead && behind_sweeps) ONMF_TRY((*behind_sweeps)());
             // a sweep evaluates the test of the one two sweeps back: the last two are still open
             ONMF_TRY(launch_screen_final(c, base, std::max(start, sub_iter - 2), sub_iter - 1, (float)tol,
-                                         (float)rank_cap, s));
+                                         (float)rank_cap, s, nullptr, cw_rows));
             for (int rd = 0; rd < dev_rounds; ++rd) {
                 const int* next = reinterpret_cast<const int*>(base) + ScreenLayout::NEXT;
                 ONMF_TRY(launch_screen_resolve(c, base, r, b, buf, sub_iter, (float)tol, s));
@@ -487,7 +492,7 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
                 ONMF_TRY(profile_mark(c, s));
                 ONMF_TRY(launch_sweep(c, r, b, Gm, Cm, buf, alpha, 0, 0, sub_iter, (double*)c->stats.p, &groups, s, &sc2));
                 ONMF_TRY(profile_mark(c, s));
-                ONMF_TRY(launch_screen_final(c, base, 0, sub_iter - 1, (float)tol, (float)rank_cap, s, next));
+                ONMF_TRY(launch_screen_final(c, base, 0, sub_iter - 1, (float)tol, (float)rank_cap, s, next, cw_rows));
             }
             // (the records, and behind them the resolution's own words: NEXT, NRES)
             HIP_TRY(c, hipMemcpyAsync(c->pinned, base + ScreenLayout::REC,
@@ -569,6 +574,16 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
                                     seed_bound ? -1.0 : (double)rec[4 * i + 3], tol, &ub_next));
                 if (dist_trace) dist_trace[i] = (float)dist;
                 if (!keep_sweeping(dist, tol)) { stop = true; break; }
+                if (i + 2 == sub_iter) {
+                    // The sweep after this one is the last, and it has run already: the sweeps were all
+                    // enqueued, and an inconclusive verdict only stops those two or more sweeps behind it
+                    // (a sweep evaluates the test two sweeps back).  Its own test decides nothing
+                    // (src/onmf.py:252: i < sub_iter), so the solve is complete, its result in place.
+                    done = sub_iter;
+                    if (dist_trace) dist_trace[i + 1] = (float)nan;       // not evaluated
+                    next_start = sub_iter;
+                    break;
+                }
                 if (i + 1 < sub_iter) {
                     ONMF_TRY(launch_screen_clear_flag(c, base, i + 1, s, (float)ub_next));
                     // the probes were not good enough to decide: one power step on this very move
@@ -583,6 +598,16 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
         // the next solve refreshes its probes if these left the bounds undecided or close to it
         c->screen_refresh_due = undecided || resolved_on_device || min_margin < 1.5;
         c->screen_last_undecided = undecided || resolved_on_device;
+        if (cw_rows > 0 && done >= 1) {
+            // ... or this one does, behind its last sweep and on that sweep's move: at once when the
+            // bounds left a test undecided (or the probes are new), every fourth solve while the
+            // tests are merely close
+            ++c->screen_since_refresh;
+            if (undecided || resolved_on_device || probes_new || (min_margin < 1.5 && c->screen_since_refresh >= 4)) {
+                ONMF_TRY(launch_screen_refresh(c, base, r, b, buf[done % 3], buf[(done + 2) % 3], s));
+                c->screen_since_refresh = 0;
+            }
+        }
         if (posted && chain_clean) {     // the device put the result in H and the follow-up work stands
             if (after_valid) *after_valid = true;
             if (sweeps_done) *sweeps_done = done;

@@ -60,6 +60,7 @@ struct onmf_ctx {
     int screen_stop = 1;
     int screen_r = -1;              // r of the probes currently held in `screen`
     bool screen_refresh_due = true; // the next screened solve runs a probe power step
+    int screen_since_refresh = 0;   // solves since the probes' last power step (ranks that refresh behind the solve)
     bool screen_last_undecided = false;   // the last screened solve needed the host for a verdict
     long long spin_limit = 200000000LL;   // bound of the sweeps' waits for each other, 100 MHz ticks (2 s)
     int persistent_sweeps = 1;      // all sweeps of a screened solve in one launch when the grid fits the chip
@@ -221,6 +222,10 @@ int launch_ndl_edge_accumulate(int n, int k, int T, const int* emb_trace, const 
 constexpr int SCREEN_MAX_SWEEPS = 64;
 constexpr int SCREEN_REPL = 8;       // replicas of the sweep kernel's accumulators (atomic contention)
 constexpr int SCREEN_ZREPL = 4;      // replicas of the power-step accumulator
+constexpr int SCREEN_YREPL = 2;      // replicas of the sweep kernel's Collatz-Wielandt accumulator
+constexpr int SCREEN_CW_ROWS = 128;  // largest (padded) r whose sweeps carry that accumulator
+// rows of that accumulator for rank r (0: the sweeps of this rank do not carry it)
+inline int screen_cw_rows(int r) { const int rp = (r + 15) / 16 * 16; return rp <= SCREEN_CW_ROWS ? rp : 0; }
 struct ScreenLayout {           // offsets in floats into ctx->screen
     static constexpr int UBLK = 0;                                 // 16 * 256: probe blocks
     static constexpr int CWV = 4096;                               // 256: positive vector of the Collatz-Wielandt bound
@@ -229,7 +234,10 @@ struct ScreenLayout {           // offsets in floats into ctx->screen
     static constexpr int SETS = ZACC + SCREEN_ZREPL * 4096;
     static constexpr int SET_P2 = 0;                               // REPL x 16 probe energies
     static constexpr int SET_SUMS = SCREEN_REPL * 16;              // REPL x 2 doubles
-    static constexpr int SETSZ = SET_SUMS + SCREEN_REPL * 4;
+    // YREPL x 128 doubles: y = H (H^T v) of the code the sweep leaves (r <= 128: Collatz-Wielandt bound
+    // of its sigma_max as a by-product of the sweep, see sweep_tile.h)
+    static constexpr int SET_Y = SET_SUMS + SCREEN_REPL * 4;
+    static constexpr int SETSZ = SET_Y + SCREEN_YREPL * 2 * SCREEN_CW_ROWS;
     static constexpr int CNT = SETS + SCREEN_MAX_SWEEPS * SETSZ;   // ints: workgroups done with sweep k
     static constexpr int UBH = CNT + SCREEN_MAX_SWEEPS;            // MAX + 1: bound of sigma_max(H before sweep k)
     static constexpr int FLAG = UBH + SCREEN_MAX_SWEEPS + 1;       // int: 0 = keep sweeping
@@ -288,10 +296,23 @@ __device__ __forceinline__ int screen_verdict(float lb2, double dsum, double hsu
 // one workgroup that writes the verdict down.  Returns the verdict, wave-uniform.
 // `seeded` >= 0: the caller has already read base[UBH + j + 1] (it may do so while it still waits for
 // the sweep's count: one memory round trip less on the way to the verdict); < 0: read it here.
+// `cw_rows` > 0: the sweep also left y = H_new (H_new^T v) in its set (rows 0 .. cw_rows - 1): with the
+// positive vector v (CWV), max_k y_k / v_k bounds sigma_max(H_new)^2 from above (Collatz-Wielandt; H_new
+// is entrywise nonnegative) - H_new is what sweep j + 1 starts from, so the bound replaces the inherited
+// one (sigma_max(H_old) + ||H_new - H_old||_F, which gives away a few per cent per sweep) when tighter.
 __device__ __forceinline__ int screen_eval_wave(float* base, int j, float& ub, float tol, float rank_cap,
-                                                bool record, float seeded_in = -1.0f) {
+                                                bool record, float seeded_in = -1.0f, int cw_rows = 0) {
     const int lane = threadIdx.x & 63;
     float* set = base + ScreenLayout::SETS + j * ScreenLayout::SETSZ;
+    float cw_ratio = 0.f;
+    for (int row = lane; row < cw_rows; row += 64) {
+        double y = 0.0;
+        for (int rp = 0; rp < SCREEN_YREPL; ++rp)
+            y += __hip_atomic_load(reinterpret_cast<double*>(set + ScreenLayout::SET_Y) + rp * SCREEN_CW_ROWS + row,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float v = base[ScreenLayout::CWV + row];
+        cw_ratio = fmaxf(cw_ratio, (float)(y / (double)v) * (1.0f + 1e-6f));
+    }
     // all loads of the wave go out together (one memory round trip): lanes 0-15 the probe energies,
     // lanes 16-31 the Frobenius sums
     float e = 0.f;
@@ -312,6 +333,10 @@ __device__ __forceinline__ int screen_eval_wave(float* base, int j, float& ub, f
         dsum += __shfl(sv, 16 + 2 * rp, 64);
         hsum += __shfl(sv, 17 + 2 * rp, 64);
     }
+    if (cw_rows > 0) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) cw_ratio = fmaxf(cw_ratio, __shfl_xor(cw_ratio, off));
+    }
     int verdict = 0;
     float ubn = ub;
     if (lane == 0) {
@@ -322,6 +347,11 @@ __device__ __forceinline__ int screen_eval_wave(float* base, int j, float& ub, f
         // or the minimum already taken with it, so all arrive at the same number
         const float seeded = seeded_in >= 0.f ? seeded_in : base[ScreenLayout::UBH + j + 1];
         if (seeded > 0.f && seeded < ubn) ubn = seeded;
+        // (1 + 1e-4 on the square: fp32 rounding of the sums behind y)
+        if (cw_ratio > 0.f && cw_ratio < 3.0e38f) {
+            const float cwb = sqrtf(cw_ratio * (1.0f + 1e-4f)) * (1.0f + 1e-6f);
+            if (cwb < ubn) ubn = cwb;
+        }
         if (record) {
             float* rec = base + ScreenLayout::REC + 4 * j;
             rec[0] = lower;
@@ -340,11 +370,14 @@ __device__ __forceinline__ int screen_eval_wave(float* base, int j, float& ub, f
 }
 #endif
 
-int launch_screen_init(onmf_ctx* c, float* base, int r, hipStream_t s);
+// n_sets: accumulator sets to clear (the solve's sweeps)
+int launch_screen_init(onmf_ctx* c, float* base, int r, hipStream_t s, int n_sets = SCREEN_MAX_SWEEPS);
 // the verdicts that no sweep of the launch evaluated: sweeps k_from .. k_last, in order
 // (start_dev not null: k_from = max(*start_dev, k_last - 1), nothing if *start_dev > k_last)
+// cw_rows: screen_cw_rows(r) when the sweeps were the tile kernel's (they carry the Collatz-Wielandt sums);
+// the kernel then also takes one power step of the positive vector on the last sweep's sums
 int launch_screen_final(onmf_ctx* c, float* base, int k_from, int k_last, float tol, float rank_cap,
-                        hipStream_t s, const int* start_dev = nullptr);
+                        hipStream_t s, const int* start_dev = nullptr, int cw_rows = 0);
 // r <= 64: settle the first inconclusive verdict in the records on the device - both Gram matrices, their
 // top eigenvalues, the reference's comparison - and prepare the launch enqueued behind it (first sweep in
 // ScreenLayout::NEXT, flag and accumulator sets reopened).  Does nothing if there is none to settle.

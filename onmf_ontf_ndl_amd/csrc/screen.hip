@@ -28,13 +28,16 @@ __device__ __forceinline__ float hash_unit(unsigned x) {      // deterministic v
     return (float)(int)(x >> 8) * (1.0f / 8388608.0f) - 1.0f;
 }
 
-__global__ __launch_bounds__(256) void screen_init_kernel(float* base, int r, int keep_probes) {
+__global__ __launch_bounds__(256) void screen_init_kernel(float* base, int r, int keep_probes, int n_sets) {
     const int tid = threadIdx.x;
     const float scale = 1.0f / sqrtf((float)r);              // |u_p|^2 <= r * scale^2 = 1
     // keep_probes: the probe vectors left by the previous solve (same r) are a better start than
     // pseudo-random ones - consecutive minibatches of a stream move the code along similar directions
     const int first = keep_probes ? ScreenLayout::ZACC : 0;
-    for (int e = first + tid; e < ScreenLayout::TOTAL; e += 256) base[e] = 0.f;
+    // (only the accumulator sets of the sweeps this solve can run)
+    const int sets_end = ScreenLayout::SETS + n_sets * ScreenLayout::SETSZ;
+    for (int e = first + tid; e < sets_end; e += 256) base[e] = 0.f;
+    for (int e = ScreenLayout::CNT + tid; e < ScreenLayout::TOTAL; e += 256) base[e] = 0.f;
     __syncthreads();
     if (tid <= SCREEN_MAX_SWEEPS) base[ScreenLayout::UBH + tid] = -1.0f;     // no bound known
     if (tid < r && !keep_probes) {
@@ -152,18 +155,54 @@ int run_refresh(onmf_ctx* c, int r, int b, const float* Hnew, const float* Hold,
 // The verdicts that no sweep evaluated (a sweep evaluates the one two sweeps back): sweeps
 // k_from .. k_last in order, up to the first that ends the loop (one wave).
 __global__ __launch_bounds__(64) void screen_final_kernel(float* base, int k_from, int k_last, float tol,
-                                                          float rank_cap, const int* start_dev) {
-    if (reinterpret_cast<const int*>(base)[ScreenLayout::FLAG] != 0) return;   // the loop ended earlier (uniform)
-    if (start_dev != nullptr) {
+                                                          float rank_cap, const int* start_dev, int cw_rows) {
+    bool open = reinterpret_cast<const int*>(base)[ScreenLayout::FLAG] == 0;   // else the loop ended earlier (uniform)
+    if (open && start_dev != nullptr) {
         // behind a launch whose first sweep came from device memory: that launch evaluated the tests from
         // its first sweep up to two before its last
         const int first = *start_dev;
-        if (first > k_last) return;
-        k_from = max(first, k_last - 1);
+        if (first > k_last) open = false;
+        else k_from = max(first, k_last - 1);
     }
-    float ub = base[ScreenLayout::UBH + k_from];
-    for (int j = k_from; j <= k_last; ++j)
-        if (screen_eval_wave(base, j, ub, tol, rank_cap, true) != 0) break;
+    if (open) {
+        float ub = base[ScreenLayout::UBH + k_from];
+        for (int j = k_from; j <= k_last; ++j)
+            if (screen_eval_wave(base, j, ub, tol, rank_cap, true, -1.0f, cw_rows) != 0) break;
+    }
+    if (cw_rows > 0) {
+        // One power step of the Collatz-Wielandt vector for the next solve, on the sums of the last sweep
+        // that ran (its count of workgroups is positive): v <- y / max y, kept strictly positive (rows of
+        // H that are all zero would zero it).  Whatever v is, the bound it gives is valid - as long as the
+        // sums were formed with the same v: so only now, after this solve's last verdict.
+        const int lane = threadIdx.x;
+        int last = -1;
+        for (int j = k_last; j >= 0 && last < 0; --j)
+            if (reinterpret_cast<const int*>(base)[ScreenLayout::CNT + j] > 0) last = j;
+        if (last >= 0) {
+            const double* yp = reinterpret_cast<const double*>(base + ScreenLayout::SETS + last * ScreenLayout::SETSZ +
+                                                               ScreenLayout::SET_Y);
+            constexpr int Q = (SCREEN_CW_ROWS + 63) / 64;
+            float y[Q], ymax = 0.f;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const int row = lane + 64 * q;
+                double t = 0.0;
+                if (row < cw_rows)
+                    for (int rp = 0; rp < SCREEN_YREPL; ++rp) t += yp[rp * SCREEN_CW_ROWS + row];
+                y[q] = (float)t;
+                ymax = fmaxf(ymax, y[q]);
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) ymax = fmaxf(ymax, __shfl_xor(ymax, off));
+            if (ymax > 0.f && ymax < 3.0e38f) {
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    const int row = lane + 64 * q;
+                    if (row < cw_rows) base[ScreenLayout::CWV + row] = fmaxf(y[q] / ymax, 1e-3f);
+                }
+            }
+        }
+    }
 }
 
 // After the last sweep of an enqueue: put the solve's result into the caller's buffer if it ended
@@ -638,17 +677,19 @@ int launch_screen_cw(onmf_ctx* c, float* base, int r, int b, const float* H, int
     return ONMF_OK;
 }
 
-int launch_screen_init(onmf_ctx* c, float* base, int r, hipStream_t s) {
+int launch_screen_init(onmf_ctx* c, float* base, int r, hipStream_t s, int n_sets) {
     const int keep = (c->screen_r == r) ? 1 : 0;
     c->screen_r = r;
-    hipLaunchKernelGGL(screen_init_kernel, dim3(1), dim3(256), 0, s, base, r, keep);
+    n_sets = std::max(1, std::min(n_sets, SCREEN_MAX_SWEEPS));
+    hipLaunchKernelGGL(screen_init_kernel, dim3(1), dim3(256), 0, s, base, r, keep, n_sets);
     HIP_TRY(c, hipGetLastError());
     return ONMF_OK;
 }
 
 int launch_screen_final(onmf_ctx* c, float* base, int k_from, int k_last, float tol, float rank_cap,
-                        hipStream_t s, const int* start_dev) {
-    hipLaunchKernelGGL(screen_final_kernel, dim3(1), dim3(64), 0, s, base, k_from, k_last, tol, rank_cap, start_dev);
+                        hipStream_t s, const int* start_dev, int cw_rows) {
+    hipLaunchKernelGGL(screen_final_kernel, dim3(1), dim3(64), 0, s, base, k_from, k_last, tol, rank_cap, start_dev,
+                       cw_rows);
     HIP_TRY(c, hipGetLastError());
     return ONMF_OK;
 }

@@ -98,6 +98,12 @@ __global__ __launch_bounds__(64 * WPG) void sweep_tile_kernel(
     float* p2wg = Us + NB * 256;           // PROBE: workgroup partial of the 16 probe energies
     double* sumwg = reinterpret_cast<double*>(p2wg + 16);   // PROBE: workgroup partial of the two sums
     int* verdict_s = reinterpret_cast<int*>(p2wg + 20);     // PROBE: verdict handed from wave 0 to the rest
+    // Collatz-Wielandt by-product (probing kernels, r <= 128): after a sweep, y = H_new (H_new^T v) for the
+    // screen's positive vector v - max_k y_k / v_k bounds sigma_max(H_new)^2, the denominator of the NEXT
+    // sweep's test, far more tightly than the bound inherited from sweep to sweep.  About 10 % more vector
+    // instructions per sweep for these small ranks, where borderline tests are frequent.
+    constexpr bool CWB = PROBE && NB <= SCREEN_CW_ROWS / 16;
+    float* ywg = p2wg + 24;                                 // CWB: 16*NB workgroup partial sums of y
 
     const int tid = threadIdx.x;
     int k_first = k_first_arg, k_count = k_count_arg, v_first = sc.v_first;
@@ -207,6 +213,13 @@ __global__ __launch_bounds__(64 * WPG) void sweep_tile_kernel(
         for (int t = 0; t < 4; ++t)
             cmn[ct][t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_c, voff[ct], t * b * 4, 0));
     float ub = PROBE ? sc.base[ScreenLayout::UBH + v_first] : -1.0f;       // bound carried by wave 0
+    float vcw[CWB ? NB : 1][4];            // CWB: the lane's rows of v (constant for the launch)
+    if constexpr (CWB) {
+#pragma unroll
+        for (int J = 0; J < NB; ++J)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) vcw[J][t] = sc.base[ScreenLayout::CWV + 16 * J + 4 * g_lane + t];
+    }
     bool active = true;                    // EACH: this lane's column is still iterating
     int col_sweeps = 0;
 
@@ -236,7 +249,7 @@ __global__ __launch_bounds__(64 * WPG) void sweep_tile_kernel(
                         __builtin_amdgcn_s_sleep(4);
                     }
                     if (verdict == 0) {
-                        verdict = screen_eval_wave(sc.base, j, ub, sc.tol, sc.rank_cap, blockIdx.x == 0, seeded);
+                        verdict = screen_eval_wave(sc.base, j, ub, sc.tol, sc.rank_cap, blockIdx.x == 0, seeded, CWB ? 16 * NB : 0);
                     } else if (lane == 0) {
                         __hip_atomic_store(reinterpret_cast<int*>(sc.base) + ScreenLayout::FLAG, verdict,
                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -259,6 +272,8 @@ __global__ __launch_bounds__(64 * WPG) void sweep_tile_kernel(
             if (PROBE) {
                 if (tid < 16) p2wg[tid] = 0.f;
                 if (tid < 2) sumwg[tid] = 0.0;
+                if (CWB)
+                    for (int j = tid; j < 16 * NB; j += NT) ywg[j] = 0.f;
             }
         }
         __syncthreads();
@@ -493,6 +508,31 @@ __global__ __launch_bounds__(64 * WPG) void sweep_tile_kernel(
                 const float e = row_sum16(e2);
                 if (c == 15) atomicAdd(&p2wg[4 * g + t], e);
             }
+            if constexpr (CWB) {
+                // t_col = v . H_new[:, col] (the lane's rows, then the four lane groups), y_row += H_new[row][col] t_col
+                float tcol[CT];
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    float p = 0.f;
+#pragma unroll
+                    for (int J = 0; J < NB; ++J)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) p = fmaf(vcw[J][t], h[ct][J][t], p);
+                    p += __shfl_xor(p, 16);
+                    p += __shfl_xor(p, 32);
+                    tcol[ct] = p;
+                }
+#pragma unroll
+                for (int J = 0; J < NB; ++J)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        float yv = 0.f;
+#pragma unroll
+                        for (int ct = 0; ct < CT; ++ct) yv = fmaf(h[ct][J][t], tcol[ct], yv);
+                        yv = row_sum16(yv);
+                        if (c == 15) atomicAdd(&ywg[16 * J + 4 * g + t], yv);
+                    }
+            }
             __syncthreads();
             // One set of global atomics per workgroup, spread over replicas to keep contention low.
             // They return, and the count below goes out only after every one of them has: whoever
@@ -506,6 +546,14 @@ __global__ __launch_bounds__(64 * WPG) void sweep_tile_kernel(
                 const double old = atomicAdd(reinterpret_cast<double*>(cur + ScreenLayout::SET_SUMS) + rep * 2 + (tid - 16),
                                              sumwg[tid - 16]);
                 asm volatile("" ::"v"(old));
+            }
+            if (CWB) {
+                const int yrep = blockIdx.x % SCREEN_YREPL;
+                for (int j = tid; j < 16 * NB; j += NT) {
+                    const double old = atomicAdd(reinterpret_cast<double*>(cur + ScreenLayout::SET_Y) +
+                                                     yrep * SCREEN_CW_ROWS + j, (double)ywg[j]);
+                    asm volatile("" ::"v"(old));
+                }
             }
             __syncthreads();
             if (tid == 0)
@@ -536,7 +584,7 @@ int run_tile(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm, float*
              int exact_cd, int k_first, int k_count, double* stats, int* n_groups, const ScreenDev& sc,
              hipStream_t s, EachStop es = EachStop{}) {
     constexpr int NBLK = HALF ? NB * (NB + 1) / 2 : NB * NB;
-    constexpr size_t lds = sizeof(float) * ((size_t)NBLK * 256 + 2 * NB * 16 + (PROBE ? (NB * 256 + 16 + 4 + 4) : 0));
+    constexpr size_t lds = sizeof(float) * ((size_t)NBLK * 256 + 2 * NB * 16 + (PROBE ? (NB * 256 + 16 + 4 + 4 + 16 * NB) : 0));
     static_assert(lds <= 160 * 1024, "Gm blocks do not fit the LDS");
     static LdsLimit lim;
     ONMF_TRY(onmf_raise_lds_limit(c, lim, (const void*)sweep_tile_kernel<NB, HALF, PROBE, CT, EACH, WPG>, lds));
