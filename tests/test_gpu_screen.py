@@ -238,3 +238,31 @@ def test_inconclusive_verdicts_are_settled_on_the_device_for_small_r(eng, d, r, 
         assert eng.counters()["device_resolves"] == before
     finally:
         eng.set_option(9, 0)
+
+
+@pytest.mark.parametrize("d,r,b", [(300, 64, 4096), (120, 25, 1000), (200, 128, 2048)])
+def test_bounds_stay_valid_and_tight_over_a_stream_of_solves(eng, d, r, b):
+    """r <= 128: the sweeps leave a Collatz-Wielandt bound of sigma_max of the new code in their sums, formed
+    with a positive vector that takes one power step per solve, and the probes take theirs behind the solve.
+    Over a stream of solves on fresh minibatches every reported value must stay a lower bound of the exact
+    dist, the sweep counts must agree with the full test - also for a threshold hugging a late sweep's
+    value - and, once vector and probes have settled, the bound must be tight (it decides tests within a
+    few per cent of the threshold: that is what it is for) on the late sweeps, where the test gets close -
+    the probes are tuned to the last move of the solve before."""
+    import torch
+    g = torch.Generator(device=eng.device).manual_seed(7 * d + r)
+    W = torch.rand(d, r, device=eng.device, generator=g)
+    W = W / torch.clamp(torch.linalg.norm(W, dim=0), min=1.0)
+    ratios = []
+    for t in range(6):
+        X = torch.rand(d, b, device=eng.device, generator=g)
+        H0 = torch.rand(r, b, device=eng.device, generator=g)
+        (He, se, de), (Hs, ss, ds) = both(eng, X, W, H0, 0.001)
+        assert ss == se == 10 and torch.equal(He, Hs)
+        for i in range(ss - 1):
+            assert ds[i] <= de[i] * (1 + 1e-3), (t, i, ds[i], de[i])
+        ratios.append(min(ds[i] / de[i] for i in range(6, 9)))
+        tol = float(de[7] * (0.98 if t % 2 else 1.02))
+        (He2, se2, de2), (Hs2, ss2, _) = both(eng, X, W, H0, tol)
+        assert ss2 == se2 and torch.equal(He2, Hs2), (t, tol, de)
+    assert max(ratios[3:]) > 0.8, ratios
