@@ -369,12 +369,13 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
         if (ps != s && tiles_m * tiles_n >= 512 && cols <= b / 4) tail_cols = cols;
     }
     int prep_rc = ONMF_OK;
+    // one stream: [W^T X | W^T W] as ONE launch and one reduction further down (they share the left operand)
+    const bool one_product = ps == s;
     if (tail_cols)   // [W^T X_tail | W^T W]: one launch and one reduction for both
         prep_rc = launch_gemm_pair(c, true, true, r, d, W, r, X + (b - tail_cols), ldx, tail_cols, W, r, r, 1.f, 0.f,
                                    nullptr, Cm + (b - tail_cols), b, 0.f, nullptr, Gm, r, ps, &c->slab_prep);
-    else
-        prep_rc = launch_gemm(c, true, true, r, r, d, W, r, W, r, 1.f, 0.f, nullptr, Gm, r, ps,
-                              ps == s ? nullptr : &c->slab_prep);
+    else if (!one_product)
+        prep_rc = launch_gemm(c, true, true, r, r, d, W, r, W, r, 1.f, 0.f, nullptr, Gm, r, ps, &c->slab_prep);
     if (prep_rc == ONMF_OK) {
         if (H0) {
             if (H0 != buf[0] &&
@@ -400,9 +401,14 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
         init_rc = onmf_reserve(c, c->screen, (size_t)ScreenLayout::TOTAL * sizeof(float), "stop-test screen");
         if (init_rc == ONMF_OK) init_rc = launch_screen_init(c, (float*)c->screen.p, r, s, sub_iter + 1);
     }
-    const int cm_rc = init_rc != ONMF_OK
-                          ? init_rc
-                          : launch_gemm(c, true, true, r, b - tail_cols, d, W, r, X, ldx, 1.f, 0.f, nullptr, Cm, b, s);
+    int cm_rc = init_rc;
+    if (cm_rc == ONMF_OK) {
+        if (one_product)
+            cm_rc = launch_gemm_pair(c, true, true, r, d, W, r, X, ldx, b, W, r, r, 1.f, 0.f, nullptr, Cm, b, 0.f, nullptr,
+                                     Gm, r, s, nullptr);
+        else
+            cm_rc = launch_gemm(c, true, true, r, b - tail_cols, d, W, r, X, ldx, 1.f, 0.f, nullptr, Cm, b, s);
+    }
     if (ps != s) {                       // always rejoin, also on an error path
         hipError_t e1 = hipEventRecord(c->ev_prep_join, ps);
         hipError_t e2 = hipStreamWaitEvent(s, c->ev_prep_join, 0);

@@ -53,10 +53,11 @@ struct GemmParams {
     int tiles_n;
     int vecA, vecB;
     float alpha, beta;
-    // optional second B operand: output columns >= n1 (a multiple of BN) contract with B2 instead
-    // (two products that share A in one launch); n1 == 0: none
+    // optional second B operand (two products that share A in one launch): the first n1 output columns
+    // contract with B, padded to n1p columns (a multiple of BN; the padding is computed on zeros and
+    // dropped), the columns from n1p on with B2; N = n1p + (columns of the second product); n1 == 0: none
     const float* B2;
-    int ldb2, n1, vecB2;
+    int ldb2, n1, n1p, vecB2;
 };
 
 // Global -> registers for one BK x 128 operand tile (4 float4 per thread).
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmParams p) {
     TileSource<A_KM> srcA;
     TileSource<B_KN> srcB;
     srcA.init(p.A, p.lda, p.M, p.K, m0, kbeg, kend, p.vecA);
-    if (p.n1 > 0 && n0 >= p.n1) srcB.init(p.B2, p.ldb2, p.N - p.n1, p.K, n0 - p.n1, kbeg, kend, p.vecB2);
+    if (p.n1 > 0 && n0 >= p.n1p) srcB.init(p.B2, p.ldb2, p.N - p.n1p, p.K, n0 - p.n1p, kbeg, kend, p.vecB2);
     else srcB.init(p.B, p.ldb, p.n1 > 0 ? p.n1 : p.N, p.K, n0, kbeg, kend, p.vecB);
     // interior workgroup of aligned operands over whole k-tiles: the branch-free loads (uniform)
     const bool sure = srcA.fast && srcB.fast && ((kend - kbeg) % BK) == 0 && ntiles > 0;
@@ -376,11 +377,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmParams p) {
 // four threads per output: thread group g adds slabs g, g+4, g+8, ... in order, the four partial sums
 // are added in order - a fixed summation order whatever the grid, so results are reproducible, and a
 // few outputs with many slabs (the small Gram matrices) still spread over the chip.
-// With n1 > 0 the columns from n1 on go to a second output (C2, ldc2) with their own beta2 * Cin2.
+// With n1 > 0 the columns below n1 go to C, those from n1p on to a second output (C2, ldc2) with their own
+// beta2 * Cin2, and those in between (padding) nowhere.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab,
                                                              int splits, int M, int N, float alpha,
                                                              float beta, const float* Cin,
-                                                             float* C, int ldc, int n1, float beta2,
+                                                             float* C, int ldc, int n1, int n1p, float beta2,
                                                              const float* Cin2, float* C2, int ldc2) {
     __shared__ float part[4][64];
     const size_t mn = (size_t)M * N;
@@ -396,8 +398,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
             const float t = ((part[0][o] + part[1][o]) + part[2][o]) + part[3][o];
             const int row = (int)(i / N), col = (int)(i % N);
             float v = alpha * t;
-            if (n1 > 0 && col >= n1) {
-                const size_t at = (size_t)row * ldc2 + (col - n1);
+            if (n1 > 0 && col >= n1 && col < n1p) {
+                // padding
+            } else if (n1 > 0 && col >= n1p) {
+                const size_t at = (size_t)row * ldc2 + (col - n1p);
                 if (beta2 != 0.f) v += beta2 * Cin2[at];
                 C2[at] = v;
             } else {
@@ -433,7 +437,7 @@ int launch_gemm(onmf_ctx* c, bool a_km, bool b_kn, int M, int N, int K, const fl
     p.alpha = alpha; p.beta = beta;
     p.vecA = (((uintptr_t)A & 15) == 0 && (lda & 3) == 0) ? 1 : 0;
     p.vecB = (((uintptr_t)B & 15) == 0 && (ldb & 3) == 0) ? 1 : 0;
-    p.B2 = nullptr; p.ldb2 = 0; p.n1 = 0; p.vecB2 = 0;
+    p.B2 = nullptr; p.ldb2 = 0; p.n1 = 0; p.n1p = 0; p.vecB2 = 0;
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     p.tiles_n = tiles_n;
     const int tiles = tiles_m * tiles_n;
@@ -471,7 +475,7 @@ int launch_gemm(onmf_ctx* c, bool a_km, bool b_kn, int M, int N, int K, const fl
         int blocks = (int)((mn + 63) / 64);
         if (blocks > 4096) blocks = 4096;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, p.slab, splits, M, N,
-                           alpha, beta, Cin, C, ldc, 0, 0.f, (const float*)nullptr, (float*)nullptr, 0);
+                           alpha, beta, Cin, C, ldc, 0, 0, 0.f, (const float*)nullptr, (float*)nullptr, 0);
         HIP_TRY(c, hipGetLastError());
     }
     return ONMF_OK;
@@ -493,12 +497,20 @@ int launch_gemm_pair(onmf_ctx* c, bool a_km, bool b_kn, int M, int K, const floa
                      float* C1, int ldc1, float beta2, const float* Cin2, float* C2, int ldc2, hipStream_t s,
                      DevBuf* slab) {
     if (!slab) slab = &c->slab;
-    const int N = N1 + N2;
+    // the product whose width is a whole number of tiles goes first: nothing to pad then
+    if ((N1 % BN) != 0 && (N2 % BN) == 0)
+        return launch_gemm_pair(c, a_km, b_kn, M, K, A, lda, B2, ldb2, N2, B1, ldb1, N1, alpha, beta2, Cin2, C2, ldc2,
+                                beta1, Cin1, C1, ldc1, s, slab);
+    const int N1p = (N1 + BN - 1) / BN * BN;          // the second product's tiles start on a tile boundary
+    const int N = N1p + N2;
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     const int tiles = tiles_m * tiles_n;
     const int ktiles = (K + BK - 1) / BK;
     int splits = (tiles > 4 && tiles < 256 && ktiles >= 4) ? std::min(SPLIT_WG_BUDGET / tiles, ktiles / 2) : 1;
-    if ((N1 % BN) != 0 || splits < 2 || (beta1 != 0.f && !Cin1) || (beta2 != 0.f && !Cin2)) {
+    // (padding of more than half a tile per row of tiles of the first product is not worth the launch saved
+    // when that product is most of the work)
+    const bool pad_ok = N1p == N1 || (N1p - N1) * 4 <= N;
+    if (!pad_ok || splits < 2 || (beta1 != 0.f && !Cin1) || (beta2 != 0.f && !Cin2)) {
         ONMF_TRY(launch_gemm(c, a_km, b_kn, M, N1, K, A, lda, B1, ldb1, alpha, beta1, Cin1, C1, ldc1, s, slab));
         return launch_gemm(c, a_km, b_kn, M, N2, K, A, lda, B2, ldb2, alpha, beta2, Cin2, C2, ldc2, s, slab);
     }
@@ -508,7 +520,7 @@ int launch_gemm_pair(onmf_ctx* c, bool a_km, bool b_kn, int M, int K, const floa
     p.alpha = alpha; p.beta = beta1;
     p.vecA = (((uintptr_t)A & 15) == 0 && (lda & 3) == 0) ? 1 : 0;
     p.vecB = (((uintptr_t)B1 & 15) == 0 && (ldb1 & 3) == 0) ? 1 : 0;
-    p.B2 = B2; p.ldb2 = ldb2; p.n1 = N1;
+    p.B2 = B2; p.ldb2 = ldb2; p.n1 = N1; p.n1p = N1p;
     p.vecB2 = (((uintptr_t)B2 & 15) == 0 && (ldb2 & 3) == 0) ? 1 : 0;
     p.tiles_n = tiles_n;
     const int kt_per = (ktiles + splits - 1) / splits;
@@ -530,7 +542,7 @@ int launch_gemm_pair(onmf_ctx* c, bool a_km, bool b_kn, int M, int K, const floa
     int blocks = (int)((mn + 63) / 64);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, p.slab, splits, M, N, alpha, beta1, Cin1,
-                       C1, ldc1, N1, beta2, Cin2, C2, ldc2);
+                       C1, ldc1, N1, N1p, beta2, Cin2, C2, ldc2);
     HIP_TRY(c, hipGetLastError());
     return ONMF_OK;
 }
