@@ -54,6 +54,9 @@ struct onmf_ctx {
     hipStream_t side = nullptr;     // dictionary pass runs here, beside the code solve
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_rec = nullptr, ev_mid = nullptr;
     hipStream_t prep = nullptr;     // the solve's small preparations run here, beside the W^T X product
+    // host memory the device can write: [0] dictionary passes redone on the device after a timeout
+    int* host_events = nullptr;
+    int* host_events_dev = nullptr;
     hipEvent_t ev_prep_fork = nullptr, ev_prep_join = nullptr;
     DevBuf slab_prep;               // split-K slabs of products issued on the preparation stream
     int overlap_dict = 1;

@@ -16,6 +16,8 @@
 // norm costs an LDS round and a barrier; it occupies a single CU and is several times faster.
 #include "common.h"
 
+#include <cstdlib>
+
 #include <algorithm>
 
 namespace {
@@ -537,6 +539,65 @@ __global__ __launch_bounds__(256) void dict_atom_scale_kernel(int d, int r, int 
     if (i < d) W[(size_t)i * r + j] = u[i] * scale;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// The pass redone on the device: enqueued behind every pass whose workgroups wait for each other,
+// it looks at that pass's timeout flag and returns at once when it is clear (the normal case: one
+// near-empty launch).  When a workgroup did give up waiting, this ONE workgroup of 256 threads (few
+// registers: it finds a place on a chip full of the products' workgroups) redoes
+// the whole pass with nobody to wait for - atom by atom, the arithmetic and summation order of
+// launch_dict_pass_serial - so the host never has to wait for a pass to learn how it went.  `events`
+// (host memory) counts the redone passes.  src: W_in, or (transposed != 0) the r x d copy the head
+// kernel staged, for an in-place pass whose W went with the discarded result.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dict_redo_kernel(int d, int r, const float* __restrict__ src, int transposed,
+                                                        const float* __restrict__ A, const float* __restrict__ B,
+                                                        float* W, const int* __restrict__ flag, int* events) {
+    if (*flag == 0) return;                                   // uniform
+    __shared__ float red[4];
+    __shared__ float part[64];                                // one partial sum of squares per 256 rows (d <= 16384)
+    const int tid = threadIdx.x;
+    if (tid == 0) __hip_atomic_fetch_add(events, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const size_t n = (size_t)d * r;
+    if (transposed) {
+        for (size_t e = tid; e < n; e += 256) W[e] = src[(e % r) * d + e / r];
+    } else if (src != W) {
+        for (size_t e = tid; e < n; e += 256) W[e] = src[e];
+    }
+    __threadfence_block();
+    __syncthreads();
+    const int nparts = (d + 255) / 256;
+    for (int j = 0; j < r; ++j) {
+        const float inv = 1.0f / (A[(size_t)j * r + j] + 1.0f);
+        // rows are independent (row i reads row i only): the unscaled entry goes straight into W
+        for (int p = 0; p < nparts; ++p) {
+            const int i = 256 * p + tid;
+            float v = 0.f;
+            if (i < d) {
+                float* wrow = W + (size_t)i * r;
+                float dot = 0.f;
+                for (int k = 0; k < r; ++k) dot = fmaf(wrow[k], A[(size_t)k * r + j], dot);
+                v = fmaxf(wrow[j] - (dot - B[(size_t)j * d + i]) * inv, 0.f);
+                wrow[j] = v;
+            }
+            const float ws = wave_sum(v * v);
+            if ((tid & 63) == 0) red[tid >> 6] = ws;
+            __syncthreads();
+            if (tid == 0) part[p] = (red[0] + red[1]) + (red[2] + red[3]);
+            __syncthreads();
+        }
+        float total = 0.f;
+        for (int p = 0; p < nparts; ++p) total += part[p];    // same order in every thread
+        const float scale = 1.0f / fmaxf(1.0f, sqrtf(total));
+        for (int p = 0; p < nparts; ++p) {
+            const int i = 256 * p + tid;
+            if (i < d) W[(size_t)i * r + j] *= scale;
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 bool dict_pass_splits(const onmf_ctx* c, int d, int r) { return d <= 16 * 1024 && c->dict_kernel != 1 && r >= 32; }
@@ -621,7 +682,6 @@ int launch_dict_pass(onmf_ctx* c, int d, int r, const float* Win, const float* A
                                    ngran + 8);
                 HIP_TRY(c, hipGetLastError());
             }
-            c->dict_coop_last = true;
         }
         if (part != 2) {
             // Qt0 = A^T W^T - B, Wt = W^T and the padded A, one launch
@@ -648,7 +708,16 @@ int launch_dict_pass(onmf_ctx* c, int d, int r, const float* Win, const float* A
 #undef PANEL_CASE
         HIP_TRY(c, hipGetLastError());
         if (part == 1) return ONMF_OK;
-        return launch_transpose(r, d, WtOut, Wout, s);
+        ONMF_TRY(launch_transpose(r, d, WtOut, Wout, s));
+        if (nwg > 1) {
+            // what to do if a workgroup gave up waiting: decided and done on the device (one near-empty
+            // launch when all went well), the host does not wait for the pass
+            const bool in_place = Win == Wout;
+            hipLaunchKernelGGL(dict_redo_kernel, dim3(1), dim3(256), 0, s, d, r, in_place ? (const float*)Wt : Win,
+                               in_place ? 1 : 0, A, B, Wout, (const int*)flag, c->host_events_dev);
+            HIP_TRY(c, hipGetLastError());
+        }
+        return ONMF_OK;
     }
     if (c->dict_kernel == 2)
         return onmf_fail(c, ONMF_ERR_ARG, "update_dict: the panel kernel covers d <= 16384 (d=%d)", d);

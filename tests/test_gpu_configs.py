@@ -156,8 +156,9 @@ def test_tall_dictionary_pass_recovers_from_a_timeout(eng, orc):
         eng.set_option(8, 2000)
         eng.set_option(7, 1)
     assert sweeps == 10
-    assert eng.counters()["dict_timeouts"] == before + 3 and eng.counters()["sweep_timeouts"] >= 1
     assert relerr(host(H), H_o) < TOL_H and relerr(host(W1), W_o) < TOL_W
+    # (the panel kernel's passes are redone and counted on the device: the count is in once the work is done)
+    assert eng.counters()["dict_timeouts"] == before + 3 and eng.counters()["sweep_timeouts"] >= 1
     assert relerr(host(A1), agg_o[0]) < TOL_AGG and relerr(host(B1), agg_o[1]) < TOL_AGG
 
 
