@@ -87,7 +87,9 @@ int onmf_aggregate(onmf_ctx* ctx, int d, int r, int b, const float* X, int ldx, 
  * For d > 1024 the pass runs on several workgroups that wait for each other's part of every atom's
  * norm (bounded waits).  If one gives up - the workgroups were not resident together - the pass is
  * redone atom by atom without such waits (slower, same result to rounding) and the event is counted
- * (ONMF_CNT_DICT_TIMEOUTS); the call synchronises `stream` for d > 1024.
+ * (ONMF_CNT_DICT_TIMEOUTS).  That happens on the device, by a kernel enqueued behind the pass: the call
+ * does not wait for the pass (ONMF_OPT_DICT_KERNEL = 1, the cross-check kernel: the host checks and redoes,
+ * and the call synchronises `stream`).
  */
 int onmf_update_dict(onmf_ctx* ctx, int d, int r, const float* W_in, const float* A, const float* B,
                      float* W_out, void* stream);
@@ -320,7 +322,8 @@ int onmf_set_option(onmf_ctx* ctx, int key, int value);
 /*
  * Event counters since onmf_create (no counterpart in the reference):
  *   ONMF_CNT_SWEEP_TIMEOUTS   one-launch solves whose workgroups gave up waiting for each other
- *   ONMF_CNT_DICT_TIMEOUTS    dictionary passes redone atom by atom for the same reason
+ *   ONMF_CNT_DICT_TIMEOUTS    dictionary passes redone atom by atom for the same reason (counted by the
+ *                             kernel that redid them: a pass still in flight is not in the count yet)
  *   ONMF_CNT_FALLBACK_SOLVES  solves that ran with one launch per sweep because of an earlier timeout
  */
 #define ONMF_CNT_SWEEP_TIMEOUTS 1
