@@ -557,7 +557,12 @@ __global__ __launch_bounds__(256) void dict_redo_kernel(int d, int r, const floa
     __shared__ float red[4];
     __shared__ float part[64];                                // one partial sum of squares per 256 rows (d <= 16384)
     const int tid = threadIdx.x;
-    if (tid == 0) __hip_atomic_fetch_add(events, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // (a load and a store, not an atomic: host memory need not support atomics from the device, and two of
+    // these workgroups at once on one context would take two timeouts on two streams)
+    if (tid == 0) {
+        const int seen = __hip_atomic_load(events, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(events, seen + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     const size_t n = (size_t)d * r;
     if (transposed) {
         for (size_t e = tid; e < n; e += 256) W[e] = src[(e % r) * d + e / r];

@@ -159,11 +159,14 @@ class Engine:
         _lib.check(rc, self.ctx, "onmf_aggregate")
         return A1, B1, C1
 
-    def update_dict(self, W, A, B):
+    def update_dict(self, W, A, B, out=None):
+        """``out``: where to put W1 (``out is W`` updates the dictionary in place)."""
         d, r = W.shape
         if tuple(A.shape) != (r, r) or tuple(B.shape) != (r, d):
             raise ValueError("update_dict: A must be (r,r) and B (r,d)")
-        W1 = self.empty(d, r)
+        W1 = self.empty(d, r) if out is None else out
+        if tuple(W1.shape) != (d, r) or not W1.is_contiguous():
+            raise ValueError("update_dict: out must be a contiguous (d,r) tensor")
         rc = self.lib.onmf_update_dict(self.ctx, d, r, _ptr(W), _ptr(A), _ptr(B), _ptr(W1),
                                        self.stream())
         _lib.check(rc, self.ctx, "onmf_update_dict")

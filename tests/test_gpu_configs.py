@@ -143,6 +143,18 @@ def test_tall_dictionary_pass_recovers_from_a_timeout(eng, orc):
             eng.set_option(6, 0)
         assert relerr(W1, want) < TOL_W
     assert eng.counters()["dict_timeouts"] == before + 2
+    # in place: the caller's W goes with the discarded result, the pass is redone from the copy the library staged
+    Wd = eng.dev(W)
+    eng.set_option(8, -2)
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            got = eng.update_dict(Wd, eng.dev(A), eng.dev(B), out=Wd)
+    finally:
+        eng.set_option(8, 2000)
+    assert got is Wd and relerr(host(Wd), want) < TOL_W
+    assert eng.counters()["dict_timeouts"] == before + 3
+    before += 1
     # and the same inside a step, where the pass runs in two parts on the side stream
     X, H0 = f32(rs, d, 300), f32(rs, r, 300)
     H_o, agg_o, W_o, _ = orc.minibatch_step(X, [A, B], W, 4, H0=H0, stopping_diff=0.0, norm="gram")
