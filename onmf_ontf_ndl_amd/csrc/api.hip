@@ -847,7 +847,17 @@ static int step_impl(onmf_ctx* c, int d, int r, int b, const float* X, int ldx, 
         // ahead of the verdict kernels, so that its workgroup is resident before those products fill
         // the chip (arriving after them it waits for one of their workgroups to end: most of their
         // duration).
-        const bool split = dict_pass_splits(c, d, r);
+        // ... unless the sweeps leave CUs free (a batch of a few thousand columns: one small workgroup per 64
+        // columns): then the whole pass runs beside the entire step, in one part.
+        if (c->cu_count == 0) {
+            int cus = 0;
+            HIP_TRY(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+            c->cu_count = cus;
+        }
+        const int dict_wgs = (d + 1023) / 1024;
+        const bool room_beside_sweeps = sweep_tile_covers(r, b) &&
+                                        sweep_tile_workgroups(c, r, b, true) + dict_wgs + 8 <= c->cu_count;
+        const bool split = dict_pass_splits(c, d, r) && !room_beside_sweeps;
         int rc = launch_dict_pass(c, d, r, W_in, dA, dB, W_out, c->side, split ? 1 : 0);
         int rc2 = ONMF_OK;
         bool agg_done = false, second_posted = !split;
