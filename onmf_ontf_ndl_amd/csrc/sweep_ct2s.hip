@@ -1,7 +1,15 @@
-// Probing tile sweep kernel with 2 tiles per wave and only 2 waves (64 columns) per workgroup, for
-// small r and small batches: a batch of a few thousand columns then spreads over four times as many
-// CUs, one wave per SIMD, instead of 8 waves taking turns on the SIMDs of a few CUs (see sweep_tile.h).
+// Probing tile sweep kernel with 64 columns per workgroup, for small r and small batches: a batch of a few
+// thousand columns then spreads over four times as many CUs instead of 8 waves taking turns on the SIMDs of
+// a few CUs (see sweep_tile.h).  One tile per wave, four waves per workgroup - one wave per SIMD, every SIMD
+// of the CU at work; with two tiles per wave (two waves per workgroup) half of the SIMDs idle and a wave has
+// twice the arithmetic per sweep (measured: d=1200 r=100 b=8192 0.365 -> 0.311 ms per step, d=1024 r=64
+// b=8192 0.26 -> 0.24).  At one wave per SIMD the LDS traffic that makes two tiles per wave pay at full
+// occupancy is no concern.
 #include "sweep_tile.h"
+
+#ifndef SMALL_CT
+#define SMALL_CT 1
+#endif
 
 bool sweep_tile_small_covers(int r) { return (r + 15) / 16 <= 8; }
 
@@ -12,7 +20,7 @@ int launch_sweep_tile_ct2_small(onmf_ctx* c, int r, int b, const float* Gm, cons
     switch ((r + 15) / 16) {
 #define SMALL_CASE(NBV)                                                                                      \
     case NBV:                                                                                                \
-        return run_tile<NBV, false, true, 2, false, 2>(c, r, b, Gm, Cm, hb, alpha, exact_cd, k_first, k_count, \
+        return run_tile<NBV, false, true, SMALL_CT, false, 128 / (32 * SMALL_CT)>(c, r, b, Gm, Cm, hb, alpha, exact_cd, k_first, k_count, \
                                                        stats, n_groups, *screen, s)
         SMALL_CASE(1);
         SMALL_CASE(2);
