@@ -11,7 +11,7 @@
 #define SMALL_CT 1
 #endif
 
-bool sweep_tile_small_covers(int r) { return (r + 15) / 16 <= 8; }
+bool sweep_tile_small_covers(int r) { return (r + 15) / 16 <= 16; }
 
 int launch_sweep_tile_ct2_small(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm, float* const* hb,
                                 float alpha, int exact_cd, int k_first, int k_count, double* stats,
@@ -20,8 +20,8 @@ int launch_sweep_tile_ct2_small(onmf_ctx* c, int r, int b, const float* Gm, cons
     switch ((r + 15) / 16) {
 #define SMALL_CASE(NBV)                                                                                      \
     case NBV:                                                                                                \
-        return run_tile<NBV, false, true, SMALL_CT, false, 128 / (32 * SMALL_CT)>(c, r, b, Gm, Cm, hb, alpha, exact_cd, k_first, k_count, \
-                                                       stats, n_groups, *screen, s)
+        return run_tile<NBV, (NBV >= 12), true, SMALL_CT, false, 128 / (32 * SMALL_CT)>(                     \
+            c, r, b, Gm, Cm, hb, alpha, exact_cd, k_first, k_count, stats, n_groups, *screen, s)
         SMALL_CASE(1);
         SMALL_CASE(2);
         SMALL_CASE(3);
@@ -30,7 +30,15 @@ int launch_sweep_tile_ct2_small(onmf_ctx* c, int r, int b, const float* Gm, cons
         SMALL_CASE(6);
         SMALL_CASE(7);
         SMALL_CASE(8);
+        SMALL_CASE(9);
+        SMALL_CASE(10);
+        SMALL_CASE(11);
+        SMALL_CASE(12);
+        SMALL_CASE(13);
+        SMALL_CASE(14);
+        SMALL_CASE(15);
+        SMALL_CASE(16);
 #undef SMALL_CASE
     }
-    return onmf_fail(c, ONMF_ERR_ARG, "sweep: the small-workgroup kernel covers r <= 128 (r=%d)", r);
+    return onmf_fail(c, ONMF_ERR_ARG, "sweep: the small-workgroup kernel covers r <= 256 (r=%d)", r);
 }
