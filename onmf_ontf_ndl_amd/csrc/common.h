@@ -201,6 +201,9 @@ int launch_sweep_tile_each4(onmf_ctx* c, int r, int b, const float* Gm, const fl
 int launch_sweep_tile_ct2_small(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm, float* const* hb,
                                 float alpha, int exact_cd, int k_first, int k_count, double* stats,
                                 int* n_groups, hipStream_t s, const ScreenDev* screen);
+int launch_sweep_tile_ct2_medium(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm, float* const* hb,
+                                float alpha, int exact_cd, int k_first, int k_count, double* stats,
+                                int* n_groups, hipStream_t s, const ScreenDev* screen);
 bool sweep_tile_small_covers(int r);
 // workgroups of a sweep launch (probing or not) for this shape: 256 columns each, or 64 each for the
 // small-workgroup probing kernel (small r, few columns)

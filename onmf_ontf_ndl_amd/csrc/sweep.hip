@@ -148,8 +148,15 @@ static bool use_small_workgroups(onmf_ctx* c, int r, int b, bool probing) {
     return probing && c->sweep_kernel == 0 && sweep_tile_small_covers(r) && (b + 63) / 64 <= cu_count(c);
 }
 
+// ... and the 128-column one when that fits and the 64-column one does not.
+static bool use_medium_workgroups(onmf_ctx* c, int r, int b, bool probing) {
+    return probing && c->sweep_kernel == 0 && !use_small_workgroups(c, r, b, probing) && (b + 127) / 128 <= cu_count(c);
+}
+
 int sweep_tile_workgroups(onmf_ctx* c, int r, int b, bool probing) {
-    return use_small_workgroups(c, r, b, probing) ? (b + 63) / 64 : (b + 255) / 256;
+    if (use_small_workgroups(c, r, b, probing)) return (b + 63) / 64;
+    if (use_medium_workgroups(c, r, b, probing)) return (b + 127) / 128;
+    return (b + 255) / 256;
 }
 
 int launch_sweep(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm, float* const* hb,
@@ -171,6 +178,9 @@ int launch_sweep(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm, fl
     if (use_small_workgroups(c, r, b, screen != nullptr))
         return launch_sweep_tile_ct2_small(c, r, b, Gm, Cm, hb, alpha, exact_cd, k_first, k_count, stats, n_groups,
                                            s, screen);
+    if (use_medium_workgroups(c, r, b, screen != nullptr))
+        return launch_sweep_tile_ct2_medium(c, r, b, Gm, Cm, hb, alpha, exact_cd, k_first, k_count, stats, n_groups,
+                                            s, screen);
     if (c->sweep_kernel == 4 || (c->sweep_kernel != 3 && screen))
         return launch_sweep_tile_ct2(c, r, b, Gm, Cm, hb, alpha, exact_cd, k_first, k_count, stats, n_groups, s,
                                      screen);

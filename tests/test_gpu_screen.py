@@ -266,3 +266,23 @@ def test_bounds_stay_valid_and_tight_over_a_stream_of_solves(eng, d, r, b):
         (He2, se2, de2), (Hs2, ss2, _) = both(eng, X, W, H0, tol)
         assert ss2 == se2 and torch.equal(He2, Hs2), (t, tol, de)
     assert max(ratios[3:]) > 0.8, ratios
+
+
+@pytest.mark.parametrize("d,r,b", [(64, 256, 3000), (50, 48, 20000), (40, 200, 17000), (64, 100, 5000)])
+def test_workgroup_geometries_agree_bit_for_bit(eng, d, r, b):
+    """The probing kernel comes with 64, 128 and 256 columns per workgroup, picked by the batch size so that
+    the sweeps spread over the chip; columns are independent, so the codes must not depend on the choice.
+    ONMF_OPT_SWEEP_KERNEL = 4 forces the 256-column form."""
+    import torch
+    g = torch.Generator(device=eng.device).manual_seed(r + b)
+    X = torch.rand(d, b, device=eng.device, generator=g)
+    W = torch.rand(d, r, device=eng.device, generator=g)
+    W = W / torch.clamp(torch.linalg.norm(W, dim=0), min=1.0)
+    H0 = torch.rand(r, b, device=eng.device, generator=g)
+    Ha, sa, _ = eng.sparse_code(X, W, H0=H0, stopping_diff=0.01)
+    eng.set_option(3, 4)
+    try:
+        Hb, sb, _ = eng.sparse_code(X, W, H0=H0, stopping_diff=0.01)
+    finally:
+        eng.set_option(3, 0)
+    assert sa == sb and torch.equal(Ha, Hb)
