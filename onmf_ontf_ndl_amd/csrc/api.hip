@@ -320,11 +320,14 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
                             int sub_iter, float stopping_diff, int coder_mode, float* H,
                             int* sweeps_done, float* dist_trace, hipStream_t s,
                             const std::function<int()>* after = nullptr, bool* after_valid = nullptr,
-                            bool second_try = false, const std::function<int()>* behind_sweeps = nullptr) {
+                            bool second_try = false, const std::function<int()>* behind_sweeps = nullptr,
+                            const std::function<int()>* behind_products = nullptr) {
     // `after`: work that consumes H (the step's aggregate products).  When the solve is enqueued as a
     // whole, it is enqueued too BEFORE the host waits for the verdicts, so the GPU does not idle
     // through that round trip; *after_valid tells the caller whether that run stands (it does not if
     // the host had to finish the solve: then the caller runs the work again).
+    // `behind_products`: other streams' work that the solve does not depend on, enqueued right after the
+    // solve's own first kernels are (the host's enqueueing is what a short step waits for).
     // `behind_sweeps`: work that must not run beside the sweeps but needs nothing of them (the step's
     // dictionary pass); it is posted right behind the last sweep launch, ahead of the verdict kernels.
     if (after_valid) *after_valid = false;
@@ -425,6 +428,7 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
         else
             cm_rc = launch_gemm(c, true, true, r, b - tail_cols, d, W, r, X, ldx, 1.f, 0.f, nullptr, Cm, b, s);
     }
+    if (behind_products && cm_rc == ONMF_OK && prep_rc == ONMF_OK) cm_rc = (*behind_products)();
     if (ps != s) {                       // always rejoin, also on an error path
         hipError_t e1 = hipEventRecord(c->ev_prep_join, ps);
         hipError_t e2 = hipStreamWaitEvent(s, c->ev_prep_join, 0);
@@ -559,7 +563,7 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
                         if (!second_try && start_intact)
                             return sparse_code_impl(c, d, r, b, X, ldx, W, H0, seed, alpha, sub_iter, stopping_diff,
                                                     coder_mode, H, sweeps_done, dist_trace, s, after, after_valid, true,
-                                                    behind_sweeps);
+                                                    behind_sweeps, nullptr);
                         return onmf_fail(c, ONMF_ERR_TIMEOUT,
                                          "sparse_code: a sweep workgroup gave up waiting for the others and the "
                                          "solve's start is gone; later solves use one launch per sweep for a while");
@@ -858,7 +862,16 @@ static int step_impl(onmf_ctx* c, int d, int r, int b, const float* X, int ldx, 
         const bool room_beside_sweeps = sweep_tile_covers(r, b) &&
                                         sweep_tile_workgroups(c, r, b, true) + dict_wgs + 8 <= c->cu_count;
         const bool split = dict_pass_splits(c, d, r) && !room_beside_sweeps;
-        int rc = launch_dict_pass(c, d, r, W_in, dA, dB, W_out, c->side, split ? 1 : 0);
+        // (a pass in one part is off the critical path altogether: it is enqueued behind the solve's first
+        // kernels - at these sizes the GPU waits for the host's enqueueing, and the pass's five launches in
+        // front of them cost the step 40 us)
+        bool whole_posted = split;
+        const std::function<int()> post_whole = [&]() {
+            if (whole_posted) return (int)ONMF_OK;
+            whole_posted = true;
+            return launch_dict_pass(c, d, r, W_in, dA, dB, W_out, c->side, 0);
+        };
+        int rc = split ? launch_dict_pass(c, d, r, W_in, dA, dB, W_out, c->side, 1) : ONMF_OK;
         int rc2 = ONMF_OK;
         bool agg_done = false, second_posted = !split;
         const std::function<int()> post_dict = [&]() {
@@ -876,7 +889,9 @@ static int step_impl(onmf_ctx* c, int d, int r, int b, const float* X, int ldx, 
         };
         if (rc == ONMF_OK)
             rc2 = sparse_code_impl(c, d, r, b, X, ldx, W_in, H0, seed, alpha, sub_iter, stopping_diff,
-                                   ONMF_CODER_DAMPED, H, sweeps_done, dist_trace, s, &agg, &agg_done, false, &post_dict);
+                                   ONMF_CODER_DAMPED, H, sweeps_done, dist_trace, s, &agg, &agg_done, false, &post_dict,
+                                   &post_whole);
+        if (rc == ONMF_OK && rc2 == ONMF_OK) rc2 = post_whole();       // (a solve that failed early did not get to it)
         if (rc == ONMF_OK && rc2 == ONMF_OK && !agg_done) rc2 = agg();
         hipError_t e1 = hipEventRecord(c->ev_join, c->side);
         // always rejoin, also on an error path, so the side stream never outlives the call's buffers
