@@ -103,10 +103,14 @@ class Engine:
             out[name] = int(v.value)
         return out
 
-    def _warn_on_timeouts(self):
+    def _warn_on_timeouts(self, now=False):
         """One warning the first time a device-side wait gave up (results stay correct; later solves are
         slower for a while).  Typical cause: another process's kernels on the same GPU."""
         if self._timeouts_seen:
+            return
+        # (looked at every 16th call: the warning can wait, a short step cannot)
+        self._calls = getattr(self, "_calls", 0) + 1
+        if (self._calls & 15) and not now:
             return
         c = self.counters()
         n = c["sweep_timeouts"] + c["dict_timeouts"]

@@ -138,6 +138,7 @@ def test_tall_dictionary_pass_recovers_from_a_timeout(eng, orc):
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore")
                 W1 = host(eng.update_dict(eng.dev(W), eng.dev(A), eng.dev(B)))
+                eng._warn_on_timeouts(now=True)      # (the engine warns once, and looks every few calls only)
         finally:
             eng.set_option(8, 2000)
             eng.set_option(6, 0)

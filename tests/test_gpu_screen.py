@@ -171,6 +171,7 @@ def test_a_timed_out_one_launch_solve_is_redone_launch_by_launch(eng):
             warnings.simplefilter("ignore")      # the engine warns once about the first timeout
             got = eng.sparse_code(X, W, H0=H0, stopping_diff=0.01)
             again = eng.sparse_code(X, W, H0=H0, stopping_diff=0.01)
+            eng._warn_on_timeouts(now=True)          # (it looks at the counters every few calls only)
     finally:
         eng.set_option(8, 2000)
         eng.set_option(PERSISTENT, 1)            # (also ends the rest the one-launch mode was sent to)
