@@ -45,6 +45,21 @@ __device__ __forceinline__ int blk_index(int K, int J) {
     return HALF ? (K * (K + 1) / 2 + J) : (K * NB + J);
 }
 
+// 4x4 exchange of a register index against the lane group (16-lane row) of a wave: afterwards register j
+// of lane group g holds what register g of lane group j held (v_permlane32_swap exchanges rows 2,3 of its
+// first operand with rows 0,1 of the second; v_permlane16_swap the odd rows of the first with the even
+// rows of the second).
+__device__ __forceinline__ void xpose_reg_group(float& r0, float& r1, float& r2, float& r3) {
+    auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(r0), __float_as_uint(r2), false, false);
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(r1), __float_as_uint(r3), false, false);
+    auto c = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
+    auto d = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
+    r0 = __uint_as_float(c[0]);
+    r1 = __uint_as_float(c[1]);
+    r2 = __uint_as_float(d[0]);
+    r3 = __uint_as_float(d[1]);
+}
+
 // sum over the 16 lanes of a DPP row (lanes 16g..16g+15); the total lands in lane 16g+15
 __device__ __forceinline__ float row_sum16(float x) {
     x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x111, 0xf, 0xf, true));
@@ -422,16 +437,25 @@ __global__ __launch_bounds__(64 * WPG) void sweep_tile_kernel(
                     }
                 }
                 if (Q < 3) {
-                    // push the four deltas into the gradients of the lane groups that come later in the
-                    // block (the groups already done take the same update: their gradients are dead)
+                    // Push the four deltas into the gradients of the lane groups that come later in the
+                    // block (the groups already done take the same update: their gradients are dead): one
+                    // MFMA per tile,  acc[16 rows][col] += G[rows][4Q .. 4Q+3] . delta[4Q .. 4Q+3][col].
+                    // Its B operand wants delta row 4Q + g in lane group g: the deltas sit in lane group Q
+                    // as registers 0..3 (zero in the other groups), so a 4 x 4 exchange of register index
+                    // against lane group (four v_permlane swaps) leaves exactly that in register Q.  The
+                    // MFMA adds its four products in row order onto the accumulator, as the sixteen
+                    // multiply-adds it replaces did (same bits); it costs 32 matrix-pipe cycles against
+                    // their 16 vector instructions and the four LDS shuffles that fed them.
+                    const float a_push = Gs[blk_index<NB, HALF>(K, K) * 256 + c * 16 + 4 * (Q ^ sw_c) + g];
     #pragma unroll
-                    for (int tj = 0; tj < 4; ++tj) {
+                    for (int ct = 0; ct < CT; ++ct) {
+                        float x0 = dq[ct][0], x1 = dq[ct][1], x2 = dq[ct][2], x3 = dq[ct][3];
+                        xpose_reg_group(x0, x1, x2, x3);
+                        const float bq = Q == 0 ? x0 : Q == 1 ? x1 : x2;
+                        f32x4 av = {acc[ct][0], acc[ct][1], acc[ct][2], acc[ct][3]};
+                        av = __builtin_amdgcn_mfma_f32_16x16x4f32(a_push, bq, av, 0, 0, 0);
     #pragma unroll
-                        for (int ct = 0; ct < CT; ++ct) {
-                            const float all = __shfl(dq[ct][tj], 16 * Q + c, 64);
-    #pragma unroll
-                            for (int t = 0; t < 4; ++t) acc[ct][t] = fmaf(Gq[t][tj], all, acc[ct][t]);
-                        }
+                        for (int t = 0; t < 4; ++t) acc[ct][t] = av[t];
                     }
                 }
             }
