@@ -60,7 +60,8 @@ const char* onmf_last_error(onmf_ctx* ctx);
  *               sweep where the test was evaluated in full; where rigorous bounds decided it, the
  *               deciding bound (a lower bound of dist if the loop went on, an upper bound if it
  *               stopped); NaN for sweeps that did not run.
- *   The radius argument r of the reference is not supported: every caller passes r=None.
+ *   The radius argument r of the reference: onmf_sparse_code_within_radius below (every caller of the
+ *               reference passes r=None, which is this entry point).
  *   coder_mode ONMF_CODER_EXACT_CD: the loop ends when ||H - H_prev||_F / ||H_prev||_F <= stopping_diff
  *               (Frobenius norms over the whole batch), tested on the last sweep of each chunk of
  *               8, 16, 32, 64, 64, ... sweeps (one launch and one host round trip per chunk), or after
@@ -71,6 +72,21 @@ int onmf_sparse_code(onmf_ctx* ctx, int d, int r, int b, const float* X, int ldx
                      const float* H0, uint64_t seed, float alpha, int sub_iter,
                      float stopping_diff, int coder_mode, float* H, int* sweeps_done,
                      float* dist_trace, void* stream);
+
+/*
+ * update_code_within_radius with r given (src/onmf.py:260-263): after every row's update the reference
+ * pulls the iterate back to within spectral distance r of H0, H1 = H0 + r / max(r, ||H1 - H0||_2) (H1 - H0),
+ * and then rebinds H0 to the iterate (line 263) - so from the second row on the distance is zero and
+ * nothing is pulled.  What the branch does is therefore: the first row's move in the first sweep is scaled
+ * by radius / max(radius, its Euclidean norm over the batch); everything else is onmf_sparse_code with the
+ * damped step.  radius must be positive and finite (0 divides by zero in the reference), r <= 640.  The
+ * stopping test is evaluated sweep by sweep (one host round trip each): no caller of the reference takes
+ * this branch, it is here for completeness, not for speed.
+ */
+int onmf_sparse_code_within_radius(onmf_ctx* ctx, int d, int r, int b, const float* X, int ldx, const float* W,
+                                   const float* H0, uint64_t seed, float radius, float alpha, int sub_iter,
+                                   float stopping_diff, float* H, int* sweeps_done, float* dist_trace,
+                                   void* stream);
 
 /*
  * Aggregate recursion of Online_NMF.step, src/onmf.py:150-158 (ontf form: src/ontf.py:147-148):

@@ -43,6 +43,9 @@ SIGNATURES = {
     "onmf_sparse_code": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, _f, C.c_int, _f, _f, C.c_uint64,
                                    C.c_float, C.c_int, C.c_float, C.c_int, _f,
                                    C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_void_p]),
+    "onmf_sparse_code_within_radius": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, _f, C.c_int, _f, _f, C.c_uint64,
+                                                 C.c_float, C.c_float, C.c_int, C.c_float, _f,
+                                                 C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_void_p]),
     "onmf_aggregate": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, _f, C.c_int, _f, C.c_double,
                                  _f, _f, _f, _f, _f, _f, C.c_void_p]),
     "onmf_update_dict": (C.c_int, [_ctx, C.c_int, C.c_int, _f, _f, _f, _f, C.c_void_p]),

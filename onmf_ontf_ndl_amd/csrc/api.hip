@@ -321,7 +321,7 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
                             int* sweeps_done, float* dist_trace, hipStream_t s,
                             const std::function<int()>* after = nullptr, bool* after_valid = nullptr,
                             bool second_try = false, const std::function<int()>* behind_sweeps = nullptr,
-                            const std::function<int()>* behind_products = nullptr) {
+                            const std::function<int()>* behind_products = nullptr, float radius = -1.f) {
     // `after`: work that consumes H (the step's aggregate products).  When the solve is enqueued as a
     // whole, it is enqueued too BEFORE the host waits for the verdicts, so the GPU does not idle
     // through that round trip; *after_valid tells the caller whether that run stands (it does not if
@@ -330,9 +330,14 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
     // solve's own first kernels are (the host's enqueueing is what a short step waits for).
     // `behind_sweeps`: work that must not run beside the sweeps but needs nothing of them (the step's
     // dictionary pass); it is posted right behind the last sweep launch, ahead of the verdict kernels.
+    // `radius` > 0: the reference's r argument (src/onmf.py:260-263), which shortens the first row's first
+    // move (see launch_sweep_radius_first); the stopping test is then evaluated per sweep.
     if (after_valid) *after_valid = false;
     if (d <= 0 || r <= 0 || b <= 0 || !X || !W || !H || ldx < b || sub_iter < 0)
         return onmf_fail(c, ONMF_ERR_ARG, "sparse_code: bad arguments (d=%d r=%d b=%d ldx=%d)", d, r, b, ldx);
+    const bool within_radius = radius > 0.f;
+    if (within_radius && (coder_mode != ONMF_CODER_DAMPED || (size_t)r * 256 > 160 * 1024))
+        return onmf_fail(c, ONMF_ERR_ARG, "sparse_code: a radius goes with the damped coder and r <= 640 (r=%d)", r);
     const size_t rb = (size_t)r * b;
     ONMF_TRY(onmf_reserve(c, c->gram, (size_t)r * r * sizeof(float), "Gm"));
     ONMF_TRY(onmf_reserve(c, c->cm, rb * sizeof(float), "Cm"));
@@ -407,7 +412,7 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
     const double tol = (double)stopping_diff;
     const double rank_cap = (double)std::min(r, b);
     const int exact_cd = (coder_mode == ONMF_CODER_EXACT_CD);
-    const bool screened = !exact_cd && tol >= 0.0 && !c->exact_stop && c->screen_stop &&
+    const bool screened = !exact_cd && !within_radius && tol >= 0.0 && !c->exact_stop && c->screen_stop &&
                           c->sweep_kernel != 1 && sweep_tile_covers(r, b) &&
                           sub_iter <= SCREEN_MAX_SWEEPS && keep_sweeping(1.0, tol);
     int init_rc = ONMF_OK;
@@ -655,7 +660,11 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
             float* nxt = buf[(done + count) % 3];
             int groups = 0;
             ONMF_TRY(profile_mark(c, s));
-            ONMF_TRY(launch_sweep(c, r, b, Gm, Cm, buf, alpha, exact_cd, done, count, (double*)c->stats.p, &groups, s));
+            if (within_radius && done == 0)
+                ONMF_TRY(launch_sweep_radius_first(c, r, b, Gm, Cm, buf[0], buf[1], alpha, radius, (double*)c->stats.p,
+                                                   &groups, s));
+            else
+                ONMF_TRY(launch_sweep(c, r, b, Gm, Cm, buf, alpha, exact_cd, done, count, (double*)c->stats.p, &groups, s));
             ONMF_TRY(profile_mark(c, s));
             HIP_TRY(c, hipMemcpyAsync(c->pinned, c->stats.p, (size_t)groups * 2 * sizeof(double),
                                       hipMemcpyDeviceToHost, s));
@@ -770,6 +779,20 @@ int onmf_sparse_code(onmf_ctx* c, int d, int r, int b, const float* X, int ldx, 
     ONMF_ENTER(c);
     ONMF_TRY(sparse_code_impl(c, d, r, b, X, ldx, W, H0, seed, alpha, sub_iter, stopping_diff,
                               coder_mode, H, sweeps_done, dist_trace, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    return ONMF_OK;
+}
+
+int onmf_sparse_code_within_radius(onmf_ctx* c, int d, int r, int b, const float* X, int ldx, const float* W,
+                                   const float* H0, uint64_t seed, float radius, float alpha, int sub_iter,
+                                   float stopping_diff, float* H, int* sweeps_done, float* dist_trace, void* stream) {
+    if (!c) return ONMF_ERR_ARG;
+    if (!(radius > 0.f) || !std::isfinite(radius))
+        return onmf_fail(c, ONMF_ERR_ARG, "sparse_code_within_radius: the radius must be positive and finite");
+    hipStream_t s = (hipStream_t)stream;
+    ONMF_ENTER(c);
+    ONMF_TRY(sparse_code_impl(c, d, r, b, X, ldx, W, H0, seed, alpha, sub_iter, stopping_diff, ONMF_CODER_DAMPED, H,
+                              sweeps_done, dist_trace, s, nullptr, nullptr, false, nullptr, nullptr, radius));
     HIP_TRY(c, hipStreamSynchronize(s));
     return ONMF_OK;
 }

@@ -191,6 +191,10 @@ int launch_sweep_tile_ct2(onmf_ctx* c, int r, int b, const float* Gm, const floa
 int launch_sweep(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm, float* const* hb,
                  float alpha, int exact_cd, int k_first, int k_count, double* stats, int* n_groups,
                  hipStream_t s, const ScreenDev* screen = nullptr);
+// Sweep 0 of a solve within a radius (src/onmf.py:260-263), by the column kernel.
+int launch_sweep_radius_first(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm, const float* Hin,
+                              float* Hout, float alpha, float radius, double* stats, int* n_groups,
+                              hipStream_t s);
 // Sweeps 0 .. sub_iter-1 in one launch, every column with its own stopping test; H in place.
 int launch_sweep_each(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm, float* H, float alpha,
                       int exact_cd, int sub_iter, EachStop es, hipStream_t s);

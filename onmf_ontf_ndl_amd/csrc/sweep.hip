@@ -17,13 +17,16 @@ __global__ __launch_bounds__(64) void sweep_column_kernel(int r, int b, const fl
                                                           const float* __restrict__ Hin,
                                                           float* __restrict__ Hout, float alpha,
                                                           float damp, int exact_cd,
-                                                          double* __restrict__ stats) {
+                                                          double* __restrict__ stats,
+                                                          const float* __restrict__ row0_scale) {
     extern __shared__ __attribute__((aligned(16))) float hs[];
     const int lane = threadIdx.x;
     const int c = blockIdx.x * 64 + lane;
     const bool valid = c < b;
     for (int k = 0; k < r; ++k) hs[k * 64 + lane] = valid ? Hin[(size_t)k * b + c] : 0.f;
     float dsum = 0.f, hsum = 0.f;
+    // the radius form: the first row's move is shortened by this factor (see radius_row0_kernel)
+    const float scale0 = row0_scale ? *row0_scale : 1.0f;
     for (int k = 0; k < r; ++k) {
         const float* __restrict__ gk = Gm + (size_t)k * r;
         float dot = 0.f;
@@ -33,7 +36,8 @@ __global__ __launch_bounds__(64) void sweep_column_kernel(int r, int b, const fl
         const float hold = hs[k * 64 + lane];
         const float cm = valid ? Cm[(size_t)k * b + c] : 0.f;
         const float grad = dot - cm + alpha;
-        const float hnew = valid ? fmaxf(hold - grad * step, 0.f) : 0.f;
+        float hnew = valid ? fmaxf(hold - grad * step, 0.f) : 0.f;
+        if (row0_scale && k == 0) hnew = hold + scale0 * (hnew - hold);
         hs[k * 64 + lane] = hnew;
         const float dl = hnew - hold;
         dsum = fmaf(dl, dl, dsum);
@@ -50,6 +54,44 @@ __global__ __launch_bounds__(64) void sweep_column_kernel(int r, int b, const fl
     if (lane == 0) {
         stats[2 * blockIdx.x + 0] = ds;
         stats[2 * blockIdx.x + 1] = hh;
+    }
+}
+
+// The radius argument of the reference's solver (src/onmf.py:260-263): after every row's update the
+// iterate is pulled back to within spectral distance `radius` of H0 - and H0 is then rebound to the
+// iterate itself (line 263), so from the second row on the distance is zero and nothing is pulled.  What
+// is left is the first row of the first sweep: its move delta (the only non-zero row of H1 - H0, whose
+// spectral norm is therefore the row's Euclidean norm) is scaled by radius / max(radius, ||delta||_2).
+// This kernel forms the squared norm of that move, one partial per workgroup in a fixed order ...
+__global__ __launch_bounds__(64) void radius_row0_kernel(int r, int b, const float* __restrict__ Gm,
+                                                         const float* __restrict__ Cm,
+                                                         const float* __restrict__ Hin, float alpha, float damp,
+                                                         double* __restrict__ partial) {
+    const int lane = threadIdx.x;
+    const int c = blockIdx.x * 64 + lane;
+    const bool valid = c < b;
+    float dot = 0.f;
+    for (int j = 0; j < r; ++j) dot = fmaf(Gm[j], valid ? Hin[(size_t)j * b + c] : 0.f, dot);
+    const float step = 1.0f / (damp * (Gm[0] + 1.0f));
+    const float hold = valid ? Hin[c] : 0.f;
+    const float grad = dot - (valid ? Cm[c] : 0.f) + alpha;
+    const float dl = valid ? fmaxf(hold - grad * step, 0.f) - hold : 0.f;
+    double ds = (double)dl * (double)dl;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ds += __shfl_xor(ds, off);
+    if (lane == 0) partial[blockIdx.x] = ds;
+}
+
+// ... and this one the factor itself.
+__global__ __launch_bounds__(64) void radius_scale_kernel(int groups, const double* __restrict__ partial, float radius,
+                                                          float* __restrict__ scale) {
+    double acc = 0.0;
+    for (int g = threadIdx.x; g < groups; g += 64) acc += partial[g];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if (threadIdx.x == 0) {
+        const double dn = sqrt(acc);
+        *scale = (float)((double)radius / fmax((double)radius, dn));
     }
 }
 
@@ -117,7 +159,7 @@ int launch_sweep_each(onmf_ctx* c, int r, int b, const float* Gm, const float* C
 
 static int launch_sweep_column(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm,
                                const float* Hin, float* Hout, float alpha, float damp, int exact_cd,
-                               double* stats, int* n_groups, hipStream_t s) {
+                               double* stats, int* n_groups, hipStream_t s, const float* row0_scale = nullptr) {
     const size_t lds = (size_t)r * 64 * sizeof(float);
     if (lds > 160 * 1024) return onmf_fail(c, ONMF_ERR_ARG, "sweep: r=%d needs %zu B of LDS", r, lds);
     static LdsLimit lim;
@@ -125,9 +167,25 @@ static int launch_sweep_column(onmf_ctx* c, int r, int b, const float* Gm, const
     const int groups = (b + 63) / 64;
     *n_groups = groups;
     hipLaunchKernelGGL(sweep_column_kernel, dim3(groups), dim3(64), lds, s, r, b, Gm, Cm, Hin, Hout,
-                       alpha, damp, exact_cd, stats);
+                       alpha, damp, exact_cd, stats, row0_scale);
     HIP_TRY(c, hipGetLastError());
     return ONMF_OK;
+}
+
+// First sweep of a solve within a radius (src/onmf.py:260-263): the factor of the first row's move, then
+// the sweep by the column kernel.  `stats` holds 2 * ceil(b/64) + 1 doubles at least.
+int launch_sweep_radius_first(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm, const float* Hin,
+                              float* Hout, float alpha, float radius, double* stats, int* n_groups,
+                              hipStream_t s) {
+    if (!(radius > 0.f)) return onmf_fail(c, ONMF_ERR_ARG, "sweep: the radius must be positive");
+    const int groups = (b + 63) / 64;
+    const float damp = (float)std::sqrt(10.0);
+    float* scale = reinterpret_cast<float*>(stats + 2 * (size_t)groups);
+    hipLaunchKernelGGL(radius_row0_kernel, dim3(groups), dim3(64), 0, s, r, b, Gm, Cm, Hin, alpha, damp, stats);
+    HIP_TRY(c, hipGetLastError());
+    hipLaunchKernelGGL(radius_scale_kernel, dim3(1), dim3(64), 0, s, groups, stats, radius, scale);
+    HIP_TRY(c, hipGetLastError());
+    return launch_sweep_column(c, r, b, Gm, Cm, Hin, Hout, alpha, damp, 0, stats, n_groups, s, scale);
 }
 
 bool sweep_tile_covers(int r, int b) {

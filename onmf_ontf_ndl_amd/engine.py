@@ -131,8 +131,9 @@ class Engine:
 
     # ------------------------------------------------------------------ the path
     def sparse_code(self, X, W, H0=None, alpha=0.0, sub_iter=10, stopping_diff=0.01, seed=None,
-                    mode=_lib.CODER_DAMPED):
-        """H (r x b), sweeps run, per-sweep dist (NaN where bounds decided) - onmf.py:233-271."""
+                    mode=_lib.CODER_DAMPED, radius=None):
+        """H (r x b), sweeps run, per-sweep dist (NaN where bounds decided) - onmf.py:233-271.
+        ``radius``: the reference's r argument (onmf.py:260-263)."""
         d, b = X.shape
         r = W.shape[1]
         if W.shape[0] != d:
@@ -144,6 +145,15 @@ class Engine:
         trace = (C.c_float * max(1, int(sub_iter)))()
         if seed is None:
             seed = self.next_seed()
+        if radius is not None:
+            if mode != _lib.CODER_DAMPED:
+                raise ValueError("sparse_code: a radius goes with the damped coder")
+            rc = self.lib.onmf_sparse_code_within_radius(self.ctx, d, r, b, _ptr(X), X.stride(0), _ptr(W), _ptr(H0),
+                                                         C.c_uint64(seed), float(radius), float(alpha),
+                                                         int(sub_iter), float(stopping_diff), _ptr(H),
+                                                         C.byref(sweeps), trace, self.stream())
+            _lib.check(rc, self.ctx, "onmf_sparse_code_within_radius")
+            return H, sweeps.value, np.array(trace[:sweeps.value], dtype=np.float64)
         rc = self.lib.onmf_sparse_code(self.ctx, d, r, b, _ptr(X), X.stride(0), _ptr(W), _ptr(H0),
                                        C.c_uint64(seed), float(alpha), int(sub_iter),
                                        float(stopping_diff), int(mode), _ptr(H), C.byref(sweeps),

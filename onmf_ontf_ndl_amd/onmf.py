@@ -225,18 +225,20 @@ def update_code_within_radius(X, W, H0=None, r=None, alpha=0, sub_iter=10, stopp
                               *, device=None, return_info=False):
     """argmin_{H>=0} |X - W H| + alpha |H| by row-wise projected Gauss-Seidel sweeps
     (src/onmf.py:233-271).  ``H0=None`` draws U[0,1) from NumPy's global generator like the
-    reference.  ``r`` (the radius) must be None: no caller of the reference ever passes one.
+    reference.  ``r`` (the radius): the reference pulls the iterate back toward H0 after every row
+    and then rebinds H0 to the iterate (src/onmf.py:260-263), which leaves one effect - the first row's
+    first move is scaled by r / max(r, its norm); that is what happens here.  ``r`` must be positive
+    (the reference divides by zero for r = 0 as soon as W has a second atom).
     ``return_info=True`` also returns (sweeps, dist_trace)."""
-    if r is not None:
-        raise NotImplementedError("update_code_within_radius: the radius restriction (r is not None) "
-                                  "is not implemented on the GPU path")
+    if r is not None and not r > 0:
+        raise ValueError("update_code_within_radius: the radius must be positive (or None)")
     eng = get_engine(device)
     like_torch = _is_torch(X)
     Xd, Wd = eng.dev(X), eng.dev(W)
     if H0 is None:
         H0 = np.random.rand(Wd.shape[1], Xd.shape[1])       # src/onmf.py:245-246
     H, sweeps, dist = eng.sparse_code(Xd, Wd, H0=eng.dev(H0), alpha=alpha, sub_iter=sub_iter,
-                                      stopping_diff=stopping_diff)
+                                      stopping_diff=stopping_diff, radius=r)
     out = _out(H, like_torch)
     return (out, sweeps, dist) if return_info else out
 

@@ -134,6 +134,41 @@ def test_g1_sparse_code(eng, kernel):
     eng.set_option(3, 0)
 
 
+def test_g1_radius_branch(eng, orc):
+    """r given (src/onmf.py:260-263): the reference's own output, then a larger case against the oracle with a
+    radius that shortens the first row's move, one that does not, and an early stop."""
+    from onmf_ontf_ndl_amd import update_code_within_radius
+    g = load_golden("g1_code")
+    X, W, H0 = g["X"][:, :6], g["W"], g["H0"][:, :6]
+    H = update_code_within_radius(X.copy(), W, H0=H0.copy(), r=0.5, alpha=0, sub_iter=3, stopping_diff=0.0)
+    assert H.dtype == np.float64 and relerr(H, g["H_radius"]) < TOL_H
+    rs = np.random.RandomState(77)
+    d, r, b = 90, 40, 333
+    X, W, H0 = rs.rand(d, b), rs.rand(d, r), rs.rand(r, b)
+    free = orc.code_sweeps(X, W, H0=H0.copy(), alpha=0.5, sub_iter=4, stopping_diff=0.0, norm="gram")
+    eng.set_option(2, 1)            # every stopping test in full, so that dist can be compared
+    for radius, tol in ((0.25, 0.0), (3.0, 0.0), (1e6, 0.0), (0.25, 0.05)):
+        trace = []
+        want = orc.code_sweeps(X, W, H0=H0.copy(), r=radius, alpha=0.5, sub_iter=4, stopping_diff=tol, norm="gram",
+                               trace=trace)
+        H, sweeps, dist = update_code_within_radius(X, W, H0=H0.copy(), r=radius, alpha=0.5, sub_iter=4,
+                                                    stopping_diff=tol, return_info=True)
+        assert sweeps == len(trace)
+        assert relerr(H, want) < TOL_H
+        np.testing.assert_allclose(dist, [t[1] for t in trace], rtol=1e-3)
+        # (the radius binds in the first two cases - the result differs from the free solve - and not in the third)
+        assert (relerr(want, free) > 1e-4) == (radius < 1e6) or tol > 0
+    eng.set_option(2, 0)
+    for kernel in (1,):                     # the fallback kernel for the later sweeps as well
+        eng.set_option(3, kernel)
+        try:
+            H = update_code_within_radius(X, W, H0=H0.copy(), r=0.25, alpha=0.5, sub_iter=4, stopping_diff=0.0)
+        finally:
+            eng.set_option(3, 0)
+        assert relerr(H, orc.code_sweeps(X, W, H0=H0.copy(), r=0.25, alpha=0.5, sub_iter=4, stopping_diff=0.0,
+                                         norm="gram")) < TOL_H
+
+
 def test_g1_bounds_decide_like_the_full_test(eng):
     g = load_golden("g1_code")
     X, W = eng.dev(g["X"]), eng.dev(g["W"])
@@ -401,8 +436,8 @@ def test_torch_in_torch_out_and_device_rng(eng):
     assert torch.isfinite(agg[0]).all() and torch.isfinite(agg[1]).all()
     H = update_code_within_radius(X, W, H0=None, r=None, alpha=1, sub_iter=10, stopping_diff=0.01)
     assert isinstance(H, torch.Tensor) and tuple(H.shape) == (8, 300) and float(H.min()) >= 0
-    with pytest.raises(NotImplementedError):
-        update_code_within_radius(X, W, r=0.5)
+    with pytest.raises(ValueError):
+        update_code_within_radius(X, W, r=0)
 
 
 def test_size_independent_properties_at_scale(eng):
