@@ -271,6 +271,12 @@ __global__ __launch_bounds__(256) void dict_head_kernel(int d, int r, int lda, c
         }
 }
 
+#ifdef ONMF_TRACE_WG
+// Diagnostic build only (tools/wg_trace.py): when and where the pass's workgroups ran.
+__device__ unsigned long long g_panel_trace[4 * 4096];
+__device__ unsigned g_panel_trace_n;
+#endif
+
 template <int RPT>
 __global__ __launch_bounds__(256) void dict_panel_kernel(int d, int r, int lda,
                                                          const float* __restrict__ Qt0,   // A^T W^T - B
@@ -285,6 +291,9 @@ __global__ __launch_bounds__(256) void dict_panel_kernel(int d, int r, int lda,
     // nwg > 1: workgroup g owns rows g * 256 RPT .. (g + 1) * 256 RPT - 1 and the workgroups exchange
     // their parts of every atom's squared norm (below); everything else is per row.
     constexpr int PW = 16;
+#ifdef ONMF_TRACE_WG
+    const unsigned long long trace_t0 = wall_clock64();
+#endif
     // a latency chain that shares its CU with workgroups of the products running beside it: its
     // instructions go first
     __builtin_amdgcn_s_setprio(3);
@@ -492,6 +501,20 @@ __global__ __launch_bounds__(256) void dict_panel_kernel(int d, int r, int lda,
             for (int m = 0; m < PW; ++m) acur[m] = anext[m];
         }
     }
+#ifdef ONMF_TRACE_WG
+    if (threadIdx.x == 0) {
+        const unsigned slot = atomicAdd(&g_panel_trace_n, 1u);
+        if (slot < 4096u) {
+            unsigned hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            g_panel_trace[4 * slot + 0] = trace_t0;
+            g_panel_trace[4 * slot + 1] = wall_clock64();
+            g_panel_trace[4 * slot + 2] = ((unsigned long long)xcc << 32) | hw;
+            g_panel_trace[4 * slot + 3] = ((unsigned long long)j_begin << 32) | (unsigned)j_end;
+        }
+    }
+#endif
 }
 
 
@@ -755,3 +778,17 @@ int launch_dict_pass(onmf_ctx* c, int d, int r, const float* Win, const float* A
     HIP_TRY(c, hipGetLastError());
     return ONMF_OK;
 }
+
+#ifdef ONMF_TRACE_WG
+extern "C" int onmf_debug_panel_trace(unsigned long long* host, int max_records) {
+    unsigned n = 0;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_panel_trace_n), sizeof(n)) != hipSuccess) return -1;
+    if (n > 4096u) n = 4096u;
+    if ((int)n > max_records) n = (unsigned)max_records;
+    if (n && hipMemcpyFromSymbol(host, HIP_SYMBOL(g_panel_trace), (size_t)n * 32) != hipSuccess) return -1;
+    const unsigned zero = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_panel_trace_n), &zero, sizeof(zero)) != hipSuccess) return -1;
+    return (int)n;
+}
+#endif

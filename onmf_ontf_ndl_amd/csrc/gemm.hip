@@ -199,9 +199,18 @@ struct TileSource {
     }
 };
 
+#ifdef ONMF_TRACE_WG
+// Diagnostic build only (tools/wg_trace.py): when and where every workgroup ran.
+__device__ unsigned long long g_wg_trace[4 * 65536];
+__device__ unsigned g_wg_trace_n;
+#endif
+
 template <bool A_KM, bool B_KN>
 __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+#ifdef ONMF_TRACE_WG
+    const unsigned long long trace_t0 = wall_clock64();
+#endif
     // layout: [A buf0][A buf1][B buf0][B buf1]
     constexpr int A_STRIDE = TILE_ELEMS;
     constexpr int B_STRIDE = TILE_ELEMS;
@@ -371,6 +380,21 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmParams p) {
             }
         }
     }
+#ifdef ONMF_TRACE_WG
+    if (threadIdx.x == 0) {
+        const unsigned slot = atomicAdd(&g_wg_trace_n, 1u);
+        if (slot < 65536u) {
+            unsigned hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            g_wg_trace[4 * slot + 0] = trace_t0;
+            g_wg_trace[4 * slot + 1] = wall_clock64();
+            g_wg_trace[4 * slot + 2] = ((unsigned long long)xcc << 32) | hw;
+            g_wg_trace[4 * slot + 3] = ((unsigned long long)gridDim.x << 32) | ((unsigned long long)gridDim.z << 20) |
+                                       (A_KM ? 2u : 0u) | (B_KN ? 1u : 0u);
+        }
+    }
+#endif
 }
 
 // Sum of the split-K slabs with the  alpha * sum + beta * Cin  epilogue.  64 outputs per workgroup,
@@ -546,3 +570,18 @@ int launch_gemm_pair(onmf_ctx* c, bool a_km, bool b_kn, int M, int K, const floa
     HIP_TRY(c, hipGetLastError());
     return ONMF_OK;
 }
+
+#ifdef ONMF_TRACE_WG
+// kind 0: copy the records out and reset the count; returns the number of records
+extern "C" int onmf_debug_gemm_trace(unsigned long long* host, int max_records) {
+    unsigned n = 0;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_wg_trace_n), sizeof(n)) != hipSuccess) return -1;
+    if (n > 65536u) n = 65536u;
+    if ((int)n > max_records) n = (unsigned)max_records;
+    if (n && hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wg_trace), (size_t)n * 32) != hipSuccess) return -1;
+    const unsigned zero = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_wg_trace_n), &zero, sizeof(zero)) != hipSuccess) return -1;
+    return (int)n;
+}
+#endif
