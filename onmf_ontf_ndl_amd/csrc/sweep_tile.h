@@ -107,8 +107,11 @@ __global__ __launch_bounds__(64 * WPG) void sweep_tile_kernel(
     constexpr int NT = 64 * WPG;           // threads per workgroup
     constexpr int WAVES = WPG;
     float* Gs = lds;                       // NBLK swizzled 16x16 blocks of Gm
-    float* steps = lds + NBLK * 256;       // 16*NB step sizes of the current sweep (0 for padded rows)
-    float* gdiag = steps + 16 * NB;        // diagonal of Gm
+    // The current sweep's step sizes, negated, as four tables of 16*NB: table Q holds the entries of the
+    // rows whose quad within their block is Q and zeros elsewhere (and zeros for padded rows) - what the
+    // lanes read while quad Q moves: their own steps in lane group Q, step 0 in the other groups.
+    float* steps = lds + NBLK * 256;
+    float* gdiag = steps + 4 * 16 * NB;    // diagonal of Gm
     float* Us = gdiag + 16 * NB;           // PROBE: NB swizzled blocks of U^T
     float* p2wg = Us + NB * 256;           // PROBE: workgroup partial of the 16 probe energies
     double* sumwg = reinterpret_cast<double*>(p2wg + 16);   // PROBE: workgroup partial of the two sums
@@ -282,7 +285,8 @@ __global__ __launch_bounds__(64 * WPG) void sweep_tile_kernel(
                     const float gjj = gdiag[j];
                     st = exact_cd ? (gjj > 0.f ? 1.0f / gjj : 0.f) : rdamp / (gjj + 1.0f);
                 }
-                steps[j] = st;
+#pragma unroll
+                for (int Q = 0; Q < 4; ++Q) steps[Q * 16 * NB + j] = (((j >> 2) & 3) == Q) ? -st : 0.f;
             }
             if (PROBE) {
                 if (tid < 16) p2wg[tid] = 0.f;
@@ -345,6 +349,12 @@ __global__ __launch_bounds__(64 * WPG) void sweep_tile_kernel(
             // the MFMA in flight lasts.  The A operand of step J + 1 is read before the MFMAs of step J.
             const int Kn = (K + 1 < NB) ? K + 1 : 0;
             constexpr int NI = 8 * CT;
+            // Transposed blocks of Gm beyond the 64 KB that an LDS instruction's offset field reaches: ONE
+            // address addition for the block's four reads, made opaque - or the compiler folds the block's
+            // offset into every read and spends an addition on each of them.  (The same for the rows of
+            // directly read blocks and for the diagonal block's quads costs more than it saves: the lane
+            // part of those addresses is recomputed per use.)
+            typedef __attribute__((address_space(3))) const float lds_cfloat;
             auto read_a = [&](int J, float (&a)[4]) {
                 if (!HALF || J <= K) {
                     const float4 v = *reinterpret_cast<const float4*>(
@@ -352,9 +362,17 @@ __global__ __launch_bounds__(64 * WPG) void sweep_tile_kernel(
                     a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w;
                 } else {
                     // Gm[16K+c][16J+4g+t] = Gm[16J+4g+t][16K+c]: rows 4g+t of block (J,K), column c
-                    const float* blk = Gs + blk_index<NB, HALF>(J, K) * 256 + 64 * g +
-                                       4 * ((c >> 2) ^ ((-g) & 3)) + (c & 3);
-                    a[0] = blk[0]; a[1] = blk[16]; a[2] = blk[32]; a[3] = blk[48];
+                    const int boff = blk_index<NB, HALF>(J, K) * 256;
+                    if (boff * 4 + 1024 <= 65536) {
+                        const float* blk = Gs + boff + 64 * g + 4 * ((c >> 2) ^ ((-g) & 3)) + (c & 3);
+                        a[0] = blk[0]; a[1] = blk[16]; a[2] = blk[32]; a[3] = blk[48];
+                    } else {
+                        unsigned addr = (unsigned)(size_t)(lds_cfloat*)(Gs + 64 * g + 4 * ((c >> 2) ^ ((-g) & 3)) + (c & 3)) +
+                                        (unsigned)boff * 4u;
+                        asm volatile("" : "+v"(addr));
+                        lds_cfloat* blk = (lds_cfloat*)(size_t)addr;
+                        a[0] = blk[0]; a[1] = blk[16]; a[2] = blk[32]; a[3] = blk[48];
+                    }
                 }
             };
             float a_cur[4], a_nxt[4];
@@ -389,12 +407,6 @@ __global__ __launch_bounds__(64 * WPG) void sweep_tile_kernel(
             __builtin_amdgcn_sched_barrier(0);
             // acc = gradient of rows 4g+t of block K (without the in-block corrections)
             float acc[CT][4], hold4[CT][4];
-            const float4 st4 = *reinterpret_cast<const float4*>(steps + 16 * K + 4 * g);
-            float st[4] = {st4.x, st4.y, st4.z, st4.w};
-            if (EACH) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) st[t] = active ? st[t] : 0.f;
-            }
     #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
     #pragma unroll
@@ -417,9 +429,12 @@ __global__ __launch_bounds__(64 * WPG) void sweep_tile_kernel(
                 }
                 // Only lane group Q moves in this quad.  The other groups run the same instructions with
                 // step 0 and floor -inf: h - 0 * grad = h, max(h, -inf) = h, delta = 0 exactly.
-                float nst[4];
+                const float4 n4 = *reinterpret_cast<const float4*>(steps + Q * 16 * NB + 16 * K + 4 * g);
+                float nst[4] = {n4.x, n4.y, n4.z, n4.w};
+                if (EACH) {
     #pragma unroll
-                for (int tj = 0; tj < 4; ++tj) nst[tj] = own ? -st[tj] : 0.f;
+                    for (int tj = 0; tj < 4; ++tj) nst[tj] = active ? nst[tj] : 0.f;
+                }
                 const float floor_q = own ? 0.f : -__builtin_inff();
                 float dq[CT][4];
     #pragma unroll
@@ -608,7 +623,7 @@ int run_tile(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm, float*
              int exact_cd, int k_first, int k_count, double* stats, int* n_groups, const ScreenDev& sc,
              hipStream_t s, EachStop es = EachStop{}) {
     constexpr int NBLK = HALF ? NB * (NB + 1) / 2 : NB * NB;
-    constexpr size_t lds = sizeof(float) * ((size_t)NBLK * 256 + 2 * NB * 16 + (PROBE ? (NB * 256 + 16 + 4 + 4 + 16 * NB) : 0));
+    constexpr size_t lds = sizeof(float) * ((size_t)NBLK * 256 + 5 * NB * 16 + (PROBE ? (NB * 256 + 16 + 4 + 4 + 16 * NB) : 0));
     static_assert(lds <= 160 * 1024, "Gm blocks do not fit the LDS");
     static LdsLimit lim;
     ONMF_TRY(onmf_raise_lds_limit(c, lim, (const void*)sweep_tile_kernel<NB, HALF, PROBE, CT, EACH, WPG>, lds));
