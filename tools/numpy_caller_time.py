@@ -12,9 +12,10 @@ from onmf_ontf_ndl_amd import Online_NMF
 from onmf_ontf_ndl_amd.engine import get_engine
 
 eng = get_engine()
-for d, r, b, n in ((100, 16, 1000, 50), (1024, 64, 8192, 20), (1024, 256, 65536, 5)):
+for d, r, b, n in ((100, 16, 1000, 60), (1024, 64, 8192, 30), (1024, 256, 65536, 6)):
     rs = np.random.RandomState(0)
-    X = rs.rand(d, b)
+    Xs = [rs.rand(d, b) for _ in range(3)]          # fresh batches in turn, as a stream brings them
+    X = Xs[0]
     W = rs.rand(d, r)
     A, B = np.zeros((r, r)), np.zeros((r, d))
     nmf = Online_NMF(X, n_components=r, iterations=2, batch_size=b)
@@ -22,26 +23,27 @@ for d, r, b, n in ((100, 16, 1000, 50), (1024, 64, 8192, 20), (1024, 256, 65536,
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for t in range(n):
-        H, agg, W1 = nmf.step(X, agg, W1, t + 2)
+        H, agg, W1 = nmf.step(Xs[t % 3], agg, W1, t + 2)
     host = (time.perf_counter() - t0) / n
     nmf_dev = Online_NMF(X, n_components=r, iterations=2, batch_size=b, rng="device", seed=1)
     nmf_dev.step(X, agg, W1, 1)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for t in range(n):
-        H, agg, W1 = nmf_dev.step(X, agg, W1, t + 2)
+        H, agg, W1 = nmf_dev.step(Xs[t % 3], agg, W1, t + 2)
     host_devrng = (time.perf_counter() - t0) / n
     t0 = time.perf_counter()
     h0 = np.random.rand(r, b)
     draw = time.perf_counter() - t0
     nmf = nmf_dev
-    Xd, Wd = eng.dev(X), eng.dev(W1)
+    Xds = [eng.dev(x) for x in Xs]
+    Xd, Wd = Xds[0], eng.dev(W1)
     Ad, Bd = eng.dev(agg[0]), eng.dev(agg[1])
     nmf.step(Xd, [Ad, Bd], Wd, 1)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for t in range(n):
-        Hd, aggd, Wd = nmf.step(Xd, [Ad, Bd], Wd, t + 2)
+        Hd, aggd, Wd = nmf.step(Xds[t % 3], [Ad, Bd], Wd, t + 2)
         Ad, Bd = aggd
     torch.cuda.synchronize()
     devt = (time.perf_counter() - t0) / n
