@@ -723,10 +723,10 @@ int launch_dict_pass(onmf_ctx* c, int d, int r, const float* Win, const float* A
         // 256 threads, thread t owns rows t, t + 256, ... of its workgroup's 1024
         const int rpt = nwg > 1 ? 4 : (d + 255) / 256;
         const int nt = rpt > 1 ? 256 : (d + 63) / 64 * 64;
-        // (The workgroup shares its CU with one workgroup of the product that runs beside it.  Claiming
-        // the CU whole - through a large LDS request - was measured: the pass gets no faster, and the
-        // product loses a second slot in that shader engine, which at 15 of 16 slots taken per engine
-        // leaves one of its workgroups waiting for the pass to end.)
+        // (At four rows per thread the workgroup takes 392 of a SIMD's 512 registers per lane, so no
+        // workgroup of the products that run beside it - 216 registers - fits on its CU: it has the CU to
+        // itself, and a product that counts on all 16 places of a shader engine leaves one workgroup
+        // waiting for the pass to end.)
 #define PANEL_CASE(RPTV)                                                                              \
     hipLaunchKernelGGL((dict_panel_kernel<RPTV>), dim3(nwg), dim3(nt), 0, s, d, r, lda, Qt, Ap, Wt, WtOut, Dt, \
                        nwg, gran, flag, spin_limit, j_begin, j_end);
