@@ -169,6 +169,24 @@ def test_g1_radius_branch(eng, orc):
                                          norm="gram")) < TOL_H
 
 
+def test_radius_entry_point_rejects_what_the_reference_cannot_run(eng):
+    """r = 0 divides by zero in the reference as soon as W has a second atom (src/onmf.py:262); the C-ABI
+    answers a radius that is not positive and finite with ONMF_ERR_ARG and a message, the engine passes that on,
+    and the radius does not combine with the exact coordinate-descent coder."""
+    import torch
+    from onmf_ontf_ndl_amd import _lib
+    X = torch.rand(20, 30, device=eng.device)
+    W = torch.rand(20, 4, device=eng.device)
+    for bad in (0.0, -1.0, float("inf"), float("nan")):
+        with pytest.raises(_lib.OnmfLibraryError, match="radius"):
+            eng.sparse_code(X, W, H0=torch.rand(4, 30, device=eng.device), radius=bad)
+    with pytest.raises(ValueError):
+        eng.sparse_code(X, W, radius=1.0, mode=_lib.CODER_EXACT_CD)
+    H, sweeps, _ = eng.sparse_code(X, W, H0=torch.rand(4, 30, device=eng.device), radius=1.0, sub_iter=3,
+                                   stopping_diff=0.0)
+    assert sweeps == 3 and float(H.min()) >= 0
+
+
 def test_g1_bounds_decide_like_the_full_test(eng):
     g = load_golden("g1_code")
     X, W = eng.dev(g["X"]), eng.dev(g["W"])
