@@ -240,6 +240,11 @@ __global__ __launch_bounds__(64 * WPG) void sweep_tile_kernel(
     }
     bool active = true;                    // EACH: this lane's column is still iterating
     int col_sweeps = 0;
+    // PROBE, wave 0: the test that the next sweep starts with is evaluated at the END of this sweep, behind
+    // this workgroup's own atomics and while they travel (their return is waited for anyway), if the count
+    // of the tested sweep is complete by then - it nearly always is.  Otherwise at the next sweep's start.
+    bool tested_ahead = false;
+    int verdict_ahead = 0;
 
     for (int k = k_first; k < k_first + k_count; ++k) {
         if (PROBE) {
@@ -250,9 +255,9 @@ __global__ __launch_bounds__(64 * WPG) void sweep_tile_kernel(
                 if (j >= v_first) {
                     const int* cnt = reinterpret_cast<const int*>(sc.base) + ScreenLayout::CNT + j;
                     // (requested together with the first look at the count; 0 = none, as negative)
-                    const float seeded = fmaxf(sc.base[ScreenLayout::UBH + j + 1], 0.f);
+                    const float seeded = tested_ahead ? 0.f : fmaxf(sc.base[ScreenLayout::UBH + j + 1], 0.f);
                     const long long t0 = wall_clock64();
-                    for (;;) {
+                    while (!tested_ahead) {
                         // (the sums are read only after the count has been seen complete: they were
                         // all in place before its last increment)
                         // (a limit of SPIN_FORCE_TIMEOUT makes the wait fail even when the count is complete:
@@ -266,7 +271,9 @@ __global__ __launch_bounds__(64 * WPG) void sweep_tile_kernel(
                         }
                         __builtin_amdgcn_s_sleep(4);
                     }
-                    if (verdict == 0) {
+                    if (tested_ahead) {
+                        verdict = verdict_ahead;
+                    } else if (verdict == 0) {
                         verdict = screen_eval_wave(sc.base, j, ub, sc.tol, sc.rank_cap, blockIdx.x == 0, seeded, CWB ? 16 * NB : 0);
                     } else if (lane == 0) {
                         __hip_atomic_store(reinterpret_cast<int*>(sc.base) + ScreenLayout::FLAG, verdict,
@@ -578,22 +585,37 @@ __global__ __launch_bounds__(64 * WPG) void sweep_tile_kernel(
             // sees the count complete finds all sums in place, without any cache maintenance.
             const int rep = blockIdx.x % SCREEN_REPL;
             float* cur = sc.base + ScreenLayout::SETS + k * ScreenLayout::SETSZ;
+            // (what the atomics return is consumed further down, behind the test evaluated ahead: the two
+            // travel together)
+            float back_f = 0.f;
+            double back_d = 0.0;
             if (tid < 16) {
-                const float old = atomicAdd(&cur[ScreenLayout::SET_P2 + rep * 16 + tid], p2wg[tid]);
-                asm volatile("" ::"v"(old));
+                back_f = atomicAdd(&cur[ScreenLayout::SET_P2 + rep * 16 + tid], p2wg[tid]);
             } else if (tid < 18) {
-                const double old = atomicAdd(reinterpret_cast<double*>(cur + ScreenLayout::SET_SUMS) + rep * 2 + (tid - 16),
-                                             sumwg[tid - 16]);
-                asm volatile("" ::"v"(old));
+                back_d = atomicAdd(reinterpret_cast<double*>(cur + ScreenLayout::SET_SUMS) + rep * 2 + (tid - 16),
+                                   sumwg[tid - 16]);
             }
             if (CWB) {
                 const int yrep = blockIdx.x % SCREEN_YREPL;
-                for (int j = tid; j < 16 * NB; j += NT) {
-                    const double old = atomicAdd(reinterpret_cast<double*>(cur + ScreenLayout::SET_Y) +
-                                                     yrep * SCREEN_CW_ROWS + j, (double)ywg[j]);
-                    asm volatile("" ::"v"(old));
+                for (int j = tid; j < 16 * NB; j += NT)
+                    back_d += atomicAdd(reinterpret_cast<double*>(cur + ScreenLayout::SET_Y) + yrep * SCREEN_CW_ROWS + j,
+                                        (double)ywg[j]);
+            }
+            tested_ahead = false;
+            if (wave == 0 && k + 1 < k_first + k_count && k - 1 >= v_first) {
+                // (whatever this reads of the seeded bound - the value put there before the launch or the
+                // minimum another workgroup has since taken with it - the test arrives at the same number)
+                const int seen = __builtin_amdgcn_readfirstlane(
+                    __hip_atomic_load(reinterpret_cast<const int*>(sc.base) + ScreenLayout::CNT + k - 1, __ATOMIC_RELAXED,
+                                      __HIP_MEMORY_SCOPE_AGENT));
+                const float seeded = fmaxf(sc.base[ScreenLayout::UBH + k], 0.f);
+                if (seen >= (int)gridDim.x && sc.spin_limit != SPIN_FORCE_TIMEOUT) {
+                    verdict_ahead = screen_eval_wave(sc.base, k - 1, ub, sc.tol, sc.rank_cap, blockIdx.x == 0, seeded,
+                                                     CWB ? 16 * NB : 0);
+                    tested_ahead = true;
                 }
             }
+            asm volatile("" ::"v"(back_f), "v"(back_d));
             __syncthreads();
             if (tid == 0)
                 __hip_atomic_fetch_add(reinterpret_cast<int*>(sc.base) + ScreenLayout::CNT + k, 1, __ATOMIC_RELAXED,
