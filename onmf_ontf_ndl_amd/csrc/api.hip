@@ -422,7 +422,13 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
         // and the few microseconds it takes let the small kernels on the other streams (Gm, the start
         // code, the head of the dictionary pass) take their places on the chip before the product's
         // workgroups fill it - behind them they would wait for its first round to finish.
+#ifdef ONMF_TRACE_WG
+        // (diagnostic build: room behind the screen state for workgroup 0's time marks, 16 per sweep)
+        init_rc = onmf_reserve(c, c->screen, ((size_t)ScreenLayout::TOTAL + 2 * 16 * SCREEN_MAX_SWEEPS + 64) * sizeof(float),
+                               "stop-test screen");
+#else
         init_rc = onmf_reserve(c, c->screen, (size_t)ScreenLayout::TOTAL * sizeof(float), "stop-test screen");
+#endif
         if (init_rc == ONMF_OK) init_rc = launch_screen_init(c, (float*)c->screen.p, r, s, sub_iter + 1);
     }
     int cm_rc = init_rc;
@@ -1213,3 +1219,15 @@ int onmf_fill_uniform(onmf_ctx* c, float* out, size_t n, uint64_t seed, void* st
 }
 
 }  // extern "C"
+
+#ifdef ONMF_TRACE_WG
+// Diagnostic build only: workgroup 0's time marks of the last screened solve (16 per sweep, 100 MHz ticks).
+extern "C" int onmf_debug_sweep_marks(onmf_ctx* c, unsigned long long* host, int max_marks) {
+    if (!c || !c->screen.p) return -1;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    const int n = std::min(max_marks, 16 * SCREEN_MAX_SWEEPS);
+    const char* src = (const char*)c->screen.p + (((size_t)ScreenLayout::TOTAL * sizeof(float) + 63) & ~(size_t)63);
+    if (hipMemcpy(host, src, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return n;
+}
+#endif

@@ -246,7 +246,18 @@ __global__ __launch_bounds__(64 * WPG) void sweep_tile_kernel(
     bool tested_ahead = false;
     int verdict_ahead = 0;
 
+#ifdef ONMF_TRACE_WG
+    // diagnostic build (tools/sweep_marks.py): workgroup 0's time marks, 16 per sweep, behind the screen state
+    unsigned long long* marks = nullptr;
+    if (PROBE && blockIdx.x == 0 && tid == 0)
+        marks = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(sc.base) +
+                                                      (((size_t)ScreenLayout::TOTAL * sizeof(float) + 63) & ~(size_t)63));
+#define SWEEP_MARK(i) do { if (marks && k < SCREEN_MAX_SWEEPS) marks[16 * k + (i)] = wall_clock64(); } while (0)
+#else
+#define SWEEP_MARK(i) do { } while (0)
+#endif
     for (int k = k_first; k < k_first + k_count; ++k) {
+        SWEEP_MARK(0);
         if (PROBE) {
             // the test of sweep k - 2, once every workgroup's sums of that sweep are in
             if (wave == 0) {
@@ -303,6 +314,7 @@ __global__ __launch_bounds__(64 * WPG) void sweep_tile_kernel(
             }
         }
         __syncthreads();
+        SWEEP_MARK(1);
         if (PROBE) {
             if (*verdict_s != 0) return;   // workgroup-uniform, and the same in every workgroup
         }
@@ -527,6 +539,7 @@ __global__ __launch_bounds__(64 * WPG) void sweep_tile_kernel(
             if (k + 1 < k_first + k_count) __syncthreads();    // the next sweep rewrites the step sizes
             continue;
         }
+        SWEEP_MARK(2);
         double ds = dsum, hh = hsum;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
@@ -579,7 +592,9 @@ __global__ __launch_bounds__(64 * WPG) void sweep_tile_kernel(
                         if (c == 15) atomicAdd(&ywg[16 * J + 4 * g + t], yv);
                     }
             }
+            SWEEP_MARK(3);
             __syncthreads();
+            SWEEP_MARK(4);
             // One set of global atomics per workgroup, spread over replicas to keep contention low.
             // They return, and the count below goes out only after every one of them has: whoever
             // sees the count complete finds all sums in place, without any cache maintenance.
@@ -609,14 +624,18 @@ __global__ __launch_bounds__(64 * WPG) void sweep_tile_kernel(
                     __hip_atomic_load(reinterpret_cast<const int*>(sc.base) + ScreenLayout::CNT + k - 1, __ATOMIC_RELAXED,
                                       __HIP_MEMORY_SCOPE_AGENT));
                 const float seeded = fmaxf(sc.base[ScreenLayout::UBH + k], 0.f);
+                SWEEP_MARK(8);
                 if (seen >= (int)gridDim.x && sc.spin_limit != SPIN_FORCE_TIMEOUT) {
                     verdict_ahead = screen_eval_wave(sc.base, k - 1, ub, sc.tol, sc.rank_cap, blockIdx.x == 0, seeded,
                                                      CWB ? 16 * NB : 0);
                     tested_ahead = true;
                 }
             }
+            SWEEP_MARK(5);
             asm volatile("" ::"v"(back_f), "v"(back_d));
+            SWEEP_MARK(6);
             __syncthreads();
+            SWEEP_MARK(7);
             if (tid == 0)
                 __hip_atomic_fetch_add(reinterpret_cast<int*>(sc.base) + ScreenLayout::CNT + k, 1, __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
