@@ -32,7 +32,7 @@ extern "C" {
 #define ONMF_ERR_NOMEM (-3)     /* scratch allocation failed                             */
 #define ONMF_ERR_TIMEOUT (-4)   /* a bounded device-side wait gave up and no retry was possible */
 
-#define ONMF_ABI_VERSION 2
+#define ONMF_ABI_VERSION 3
 
 /* coder_mode of onmf_sparse_code */
 #define ONMF_CODER_DAMPED 0 /* reference step 1/(sqrt(i+10)(G_kk+1)), src/onmf.py:257       */
@@ -196,6 +196,27 @@ int onmf_sparse_code_each(onmf_ctx* ctx, int d, int r, int b, const float* X, in
                           const float* H0, uint64_t seed, float alpha, int sub_iter,
                           float stopping_diff, int coder_mode, float* H, int32_t* sweeps_each,
                           void* stream);
+
+/*
+ * Online_NTF.joint_sparse_code_tensor(X, W), src/ontf.py:59-89: scikit-learn's
+ *   SparseCoder(dictionary=W.T, transform_alpha=alpha, transform_algorithm='lasso_lars', positive_code=True)
+ *     .transform(X.T)
+ * followed event by event, one column per wavefront: the positive LARS-lasso path of
+ * sklearn.linear_model._least_angle._lars_path_solver (scikit-learn 1.7.2: method="lasso", positive=True,
+ * Gram = W^T W and Xy = W^T x precomputed, alpha_min = alpha / d, return_path=False) including the way it
+ * ends - the library's path stops short of the optimum of the convex problem once no atom with a positive
+ * correlation is left, and the reference's aggregates are built from those codes.  W^T W and W^T X are
+ * accumulated in double from the float operands, the path itself runs in double.
+ *   alpha     the reference's `alpha` (2 when it is None, src/ontf.py:79-81); must be >= 0
+ *   max_iter  the library's event limit (SparseCoder's transform_max_iter, 1000 by default)
+ *   H         r x b out (the reference returns the transpose, b x r)
+ *   info      device int32[4*b], nullable: per column {events, end (1: alpha reached, 2: every atom active
+ *             or max_iter, 3: the library's "alpha is increasing" bail-out, 4: safety limit), active atoms at
+ *             the end, atoms that left the active set on the way}
+ * r <= 256.  Asynchronous on `stream`, returns no host scalars.
+ */
+int onmf_sparse_code_lars(onmf_ctx* ctx, int d, int r, int b, const float* X, int ldx, const float* W,
+                          double alpha, int max_iter, float* H, int32_t* info, void* stream);
 
 /* R = W H (d x b, leading dimension ldr): np.dot(self.W, code), image_reconstruction.py:352, :385. */
 int onmf_patch_product(onmf_ctx* ctx, int d, int r, int b, const float* W, const float* H, float* R,

@@ -148,7 +148,7 @@ int onmf_destroy(onmf_ctx* c) {
     (void)hipDeviceSynchronize();
     DevBuf* bufs[] = {&c->slab, &c->cm, &c->gram, &c->hbuf[0], &c->hbuf[1], &c->stats, &c->small,
                       &c->qt, &c->sync, &c->idx, &c->dbuf, &c->slab_side, &c->screen, &c->ddelta, &c->slab_prep,
-                      &c->gstack, &c->rslab};
+                      &c->gstack, &c->rslab, &c->gram64, &c->cm64, &c->lars_ws};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (c->pinned) (void)hipHostFree(c->pinned);
@@ -1085,6 +1085,24 @@ int onmf_sparse_code_each(onmf_ctx* c, int d, int r, int b, const float* X, int 
     }
     EachStop es = {stopping_diff, sweeps_each};
     return launch_sweep_each(c, r, b, Gm, Cm, H, alpha, coder_mode == ONMF_CODER_EXACT_CD, sub_iter, es, s);
+}
+
+int onmf_sparse_code_lars(onmf_ctx* c, int d, int r, int b, const float* X, int ldx, const float* W, double alpha,
+                          int max_iter, float* H, int32_t* info, void* stream) {
+    if (!c) return ONMF_ERR_ARG;
+    if (d <= 0 || r <= 0 || b <= 0 || !X || !W || !H || ldx < b || max_iter < 0 || !(alpha >= 0.0) || r > 256)
+        return onmf_fail(c, ONMF_ERR_ARG, "sparse_code_lars: bad arguments (d=%d r=%d b=%d ldx=%d alpha=%g)", d, r, b,
+                         ldx, alpha);
+    hipStream_t s = (hipStream_t)stream;
+    ONMF_ENTER(c);
+    ONMF_TRY(onmf_reserve(c, c->gram64, (size_t)r * r * sizeof(double), "Gm (double)"));
+    ONMF_TRY(onmf_reserve(c, c->cm64, (size_t)r * b * sizeof(double), "Cm (double)"));
+    double* Gd = (double*)c->gram64.p;
+    double* Cd = (double*)c->cm64.p;
+    // the Gram matrix and the correlations the library is handed (_dict_learning.py: gram = W^T W, cov = W^T X)
+    ONMF_TRY(launch_prod_f64(c, r, r, d, W, r, W, r, Gd, r, s));
+    ONMF_TRY(launch_prod_f64(c, r, b, d, W, r, X, ldx, Cd, b, s));
+    return launch_lars_pos(c, r, b, Gd, Cd, b, alpha, (double)d, max_iter, H, b, info, s);
 }
 
 int onmf_patch_product(onmf_ctx* c, int d, int r, int b, const float* W, const float* H, float* R, int ldr,

@@ -80,6 +80,8 @@ struct onmf_ctx {
     long long n_dict_timeouts = 0;        // dictionary passes whose workgroups gave up waiting for each other
     long long n_fallback_solves = 0;      // solves run with one launch per sweep because of an earlier timeout
     float* static_scratch = nullptr;      // this device's copy of the library's static scratch array
+    // positive-LARS coder: W^T W and W^T X accumulated in double, per-wave inverses that do not fit in LDS
+    DevBuf gram64, cm64, lars_ws;
 };
 
 // Makes the context's device current for the duration of an entry point and puts the caller's back
@@ -423,6 +425,14 @@ int launch_dict_pass_serial(onmf_ctx* c, int d, int r, const float* Win, const f
                             float* Wout, hipStream_t s);
 // W^T as the last panel-kernel pass staged it (valid after launch_dict_pass on the panel path)
 const float* dict_staged_wt(const onmf_ctx* c, int d, int r);
+
+// Out (M x N, double) = A^T B for float operands stored contraction-major (A[k*lda + m], B[k*ldb + n])
+int launch_prod_f64(onmf_ctx* c, int M, int N, int K, const float* A, int lda, const float* B, int ldb, double* Out,
+                    int ldo, hipStream_t s);
+// scikit-learn's positive LARS-lasso path per column (lars.hip): G (r x r), Cd (r x b, leading dimension
+// ldc) in double; H (r x b, leading dimension ldh) out; info: device int[4*b] or null
+int launch_lars_pos(onmf_ctx* c, int r, int b, const double* G, const double* Cd, int ldc, double alpha,
+                    double n_samples, int max_iter, float* H, int ldh, int* info, hipStream_t s);
 
 int launch_fill_uniform(float* out, size_t n, uint64_t seed, hipStream_t s);
 int launch_gather_columns(int d, int n, const float* X, int ldx, const long long* idx, int b,

@@ -1,0 +1,565 @@
+// Positive LARS-lasso coder of Online_NTF on gfx950.
+//
+// The reference hands every column of a minibatch to scikit-learn (src/ontf.py:79-86):
+//   SparseCoder(dictionary=W.T, transform_alpha=alpha or 2, transform_algorithm='lasso_lars',
+//               positive_code=True).transform(X.T)
+// which runs, per column, sklearn.linear_model._least_angle._lars_path_solver with method="lasso",
+// positive=True, a precomputed Gram matrix W^T W and Xy = W^T x, return_path=False, alpha_min = alpha / d.
+// That routine does NOT end at the optimum of the convex problem: when it runs out of atoms with a positive
+// correlation it takes the largest correlation among the INACTIVE atoms for the active set's common
+// correlation and interpolates the last segment with it.  The learned dictionary depends on those codes, so
+// this file follows the routine event by event instead of solving the convex problem:
+//   * `lars_pos_kernel`: one column per wavefront.  Where the library keeps a Cholesky factor of the active
+//     Gram matrix and solves two triangular systems per event (two dependent chains per event), this kernel
+//     keeps the INVERSE of the active Gram matrix, updated by one symmetric rank-one step when an atom
+//     enters or leaves - every pass over it is a loop of independent row operations across the lanes.
+//     All of the column's state is double precision: the inverse (packed symmetric in LDS, a slot per
+//     active atom, freed slots reused; in a global workspace when it does not fit), the correlations, the
+//     coefficients.  Lane l owns atoms l, l + 64, ... and slots l, l + 64, ...
+//   * `prod_f64_kernel`: W^T W and W^T X accumulated in double (`v_mfma_f64_16x16x4_f64`) from the float
+//     operands.  With float accumulation the rounding of the two products alone moves the codes by
+//     2e-5 ... 2e-4 (the active Gram matrices have condition numbers of 1e3 ... 1e4); in double the codes
+//     follow the reference's to 1e-7.
+// Deviations from the routine, all at the level of exact ties or rounding: ties of the largest correlation
+// go to the lowest atom index (the routine: first in its permuted order); correlations are not rounded to
+// 15 decimals; atoms that reach zero in the same event all leave (the routine miscounts them); after a
+// degenerate pivot (< 1e-7) the atom's correlation is zeroed and nothing else is permuted.
+#include "common.h"
+
+#include <cfloat>
+#include <climits>
+
+namespace {
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------
+// Out[m][n] = sum_k A[k*lda + m] * B[k*ldb + n]   (float operands, double accumulation and result)
+// 64 x 64 output tile per workgroup of four waves; wave w: rows 16w .. 16w+15, four 16-column blocks.
+// ---------------------------------------------------------------------------------------------
+constexpr int PT = 64, PK = 16, PPITCH = 80;
+
+__global__ __launch_bounds__(256) void prod_f64_kernel(int M, int N, int K, const float* __restrict__ A, int lda,
+                                                       const float* __restrict__ B, int ldb,
+                                                       double* __restrict__ Out, int ldo) {
+    __shared__ float sa[PK * PPITCH], sb[PK * PPITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * PT, n0 = blockIdx.x * PT;
+    f64x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = f64x4{0.0, 0.0, 0.0, 0.0};
+    const int lk = tid >> 4, lx = (tid & 15) * 4;
+    float ra[4], rb[4];
+    auto fetch = [&](int k0) {
+        const int k = k0 + lk;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + lx + i, n = n0 + lx + i;
+            ra[i] = (k < K && m < M) ? A[(size_t)k * lda + m] : 0.f;
+            rb[i] = (k < K && n < N) ? B[(size_t)k * ldb + n] : 0.f;
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < K; k0 += PK) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            sa[lk * PPITCH + lx + i] = ra[i];
+            sb[lk * PPITCH + lx + i] = rb[i];
+        }
+        __syncthreads();
+        if (k0 + PK < K) fetch(k0 + PK);
+#pragma unroll
+        for (int kk = 0; kk < PK / 4; ++kk) {
+            const int krow = (kk * 4 + (lane >> 4)) * PPITCH;
+            const double av = (double)sa[krow + wave * 16 + (lane & 15)];
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                const double bv = (double)sb[krow + nb * 16 + (lane & 15)];
+                acc[nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[nb], 0, 0, 0);
+            }
+        }
+    }
+    // result register i of a lane: row (lane >> 4) + 4 i, column lane & 15 of the 16 x 16 block
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        const int n = n0 + nb * 16 + (lane & 15);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + wave * 16 + (lane >> 4) + 4 * i;
+            if (m < M && n < N) Out[(size_t)m * ldo + n] = acc[nb][i];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// wave-wide helpers on doubles (butterflies: every lane ends with the same bits)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off));
+    return v;
+}
+// largest value, lowest index among equals
+__device__ __forceinline__ void wave_argmax(double& v, int& idx) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ov = __shfl_xor(v, off);
+        const int oi = __shfl_xor(idx, off);
+        if (ov > v || (ov == v && oi < idx)) {
+            v = ov;
+            idx = oi;
+        }
+    }
+}
+__device__ __forceinline__ double lane_value(double v, int l) {       // l wave-uniform
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ double uni(double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)),
+                            __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+// what one pass over the inverse wrote must be visible to the next pass's lanes (same wave)
+__device__ __forceinline__ void pass_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
+struct LarsArgs {
+    int r, b;
+    const double* G;        // r x r
+    const double* Cd;       // r x ldc: column c = W^T x_c
+    int ldc;
+    double alpha;           // transform_alpha (the penalty of the convex problem)
+    double n_samples;       // d: the library scales the penalty and the path's alphas by it
+    int max_iter;
+    float* H;               // r x ldh out
+    int ldh;
+    int* info;              // nullable: per column {events, how the path ended (1 alpha reached, 2 all atoms
+                            // active or event limit, 3 alpha went up), active atoms, atoms dropped}
+    double* Pws;            // global workspace of the inverse (P_LDS == false), p_stride doubles per wave
+    size_t p_stride;
+    int wave_doubles;       // LDS doubles per wave
+};
+
+// The inverse of the active Gram matrix, indexed by slot.  PACKED: lower triangle, row after row (LDS);
+// else a full square with leading dimension 64 Q (global memory: rows are read coalesced).
+template <bool PACKED>
+struct Inv {
+    double* p;
+    int ld;
+    __device__ __forceinline__ double& at(int i, int j) const {
+        if (PACKED) {
+            const int hi = i >= j ? i : j, lo = i >= j ? j : i;
+            return p[(hi * (hi + 1) >> 1) + lo];
+        }
+        return p[(size_t)i * ld + j];
+    }
+    // the lane of column j changes entry (i, j) of row i: in packed form each entry exists once
+    __device__ __forceinline__ bool mine(int i, int j) const { return PACKED ? j <= i : true; }
+};
+
+template <int Q, bool P_LDS>
+__global__ __launch_bounds__(256) void lars_pos_kernel(const LarsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double lds_raw[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpg = blockDim.x >> 6;
+    const int r = a.r;
+    double* lsv = lds_raw + (size_t)wave * a.wave_doubles;      // direction by slot (r doubles)
+    Inv<P_LDS> P;
+    if (P_LDS) {
+        P.p = lsv + ((r + 1) & ~1);
+        P.ld = 0;
+    } else {
+        P.p = a.Pws + (size_t)(blockIdx.x * wpg + wave) * a.p_stride;
+        P.ld = 64 * Q;
+    }
+    const double* __restrict__ G = a.G;
+    const double tiny32 = (double)FLT_MIN, eq_tol = (double)FLT_EPSILON;
+    const double alpha_min = a.alpha / a.n_samples;
+
+    for (int col = blockIdx.x * wpg + wave; col < a.b; col += gridDim.x * wpg) {
+        // atom space (atom j = lane + 64 q)
+        double xy[Q], cov[Q], coef[Q], prev[Q];
+        int slot[Q];
+        // slot space (slot k = lane + 64 q)
+        int act[Q];
+        double w[Q];
+        unsigned long long used[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int j = lane + 64 * q;
+            xy[q] = j < r ? a.Cd[(size_t)j * a.ldc + col] : 0.0;
+            cov[q] = xy[q];
+            coef[q] = prev[q] = 0.0;
+            slot[q] = -1;
+            act[q] = 0;
+            w[q] = 0.0;
+            used[q] = 0ull;
+        }
+        int n_active = 0, n_iter = 0, n_drops = 0, end = 0;
+        // every trip of the loop below is an event or a skipped degenerate atom (at most r of those between
+        // two events in the library; the bound makes sure that every wave leaves the loop whatever the data)
+        int trips_left = a.max_iter + 2 * r + 8;
+        bool drop = false;
+        double alpha = 0.0, prev_alpha = 0.0;
+
+        auto slot_used = [&](int q) -> bool { return (used[q] >> lane) & 1ull; };
+        // w = column sums of the inverse over the used slots
+        auto column_sums = [&]() {
+#pragma unroll
+            for (int q = 0; q < Q; ++q) w[q] = 0.0;
+#pragma unroll
+            for (int qi = 0; qi < Q; ++qi) {
+                unsigned long long m = used[qi];
+                while (m) {
+                    const int ii = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const int i = 64 * qi + ii;
+#pragma unroll
+                    for (int q = 0; q < Q; ++q)
+                        if (slot_used(q)) w[q] += P.at(i, lane + 64 * q);
+                }
+            }
+        };
+
+        for (;;) {
+            // largest correlation among the inactive atoms (_least_angle.py:634-647)
+            double C = -DBL_MAX;
+            int c_idx = INT_MAX;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const int j = lane + 64 * q;
+                if (j < r && slot[q] < 0 && cov[q] > C) {
+                    C = cov[q];
+                    c_idx = j;
+                }
+            }
+            wave_argmax(C, c_idx);
+            c_idx = uni(c_idx);
+            C = uni(C);
+            if (n_active >= r) C = 0.0;
+            alpha = C / a.n_samples;
+            if (alpha <= alpha_min + eq_tol) {                       // :656-667
+                if (fabs(alpha - alpha_min) > eq_tol && n_iter > 0) {
+                    const double ss = (prev_alpha - alpha_min) / (prev_alpha - alpha);
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) coef[q] = prev[q] + ss * (coef[q] - prev[q]);
+                }
+                end = 1;
+                break;
+            }
+            if (n_iter >= a.max_iter || n_active >= r) {             // :669-670
+                end = 2;
+                break;
+            }
+            if (--trips_left < 0) {
+                end = 4;
+                break;
+            }
+            if (!drop) {                                             // :671-741: atom c_idx enters
+                const int v = c_idx;
+                double g[Q], u[Q];
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    g[q] = slot_used(q) ? G[(size_t)v * r + act[q]] : 0.0;
+                    u[q] = 0.0;
+                }
+                // u = inverse . g
+#pragma unroll
+                for (int qi = 0; qi < Q; ++qi) {
+                    unsigned long long m = used[qi];
+                    while (m) {
+                        const int ii = __builtin_ctzll(m);
+                        m &= m - 1;
+                        const int i = 64 * qi + ii;
+                        const double gi = lane_value(g[qi], ii);
+#pragma unroll
+                        for (int q = 0; q < Q; ++q)
+                            if (slot_used(q)) u[q] += P.at(i, lane + 64 * q) * gi;
+                    }
+                }
+                double gu = 0.0;
+#pragma unroll
+                for (int q = 0; q < Q; ++q) gu += g[q] * u[q];
+                gu = wave_sum(gu);
+                const double s = G[(size_t)v * r + v] - gu;          // Schur complement = pivot^2 (:715-717)
+                const double diag = fmax(sqrt(fabs(s)), DBL_EPSILON);
+                if (diag < 1e-7) {                                   // :719-738
+#pragma unroll
+                    for (int q = 0; q < Q; ++q)
+                        if (lane + 64 * q == v) cov[q] = 0.0;
+                    continue;
+                }
+                const double sinv = 1.0 / (diag * diag);
+                int knew = 0;
+#pragma unroll
+                for (int q = Q - 1; q >= 0; --q)
+                    if (~used[q]) knew = 64 * q + __builtin_ctzll(~used[q]);
+                // inverse += u u^T / s over the used slots; the new slot's row and column
+#pragma unroll
+                for (int qi = 0; qi < Q; ++qi) {
+                    unsigned long long m = used[qi];
+                    while (m) {
+                        const int ii = __builtin_ctzll(m);
+                        m &= m - 1;
+                        const int i = 64 * qi + ii;
+                        const double ui = lane_value(u[qi], ii);
+#pragma unroll
+                        for (int q = 0; q < Q; ++q) {
+                            const int k = lane + 64 * q;
+                            if (slot_used(q) && P.mine(i, k)) P.at(i, k) += (ui * u[q]) * sinv;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    const int k = lane + 64 * q;
+                    if (slot_used(q)) {
+                        P.at(knew, k) = -u[q] * sinv;
+                        if (!P_LDS) P.at(k, knew) = -u[q] * sinv;
+                    }
+                    if (k == knew) {
+                        P.at(knew, knew) = sinv;
+                        act[q] = v;
+                    }
+                    if (lane + 64 * q == v) slot[q] = knew;
+                }
+#pragma unroll
+                for (int q = 0; q < Q; ++q)
+                    if ((knew >> 6) == q) used[q] |= 1ull << (knew & 63);
+                ++n_active;
+                pass_fence();
+                column_sums();
+            }
+            if (n_iter > 0 && prev_alpha < alpha) {                  // :748-761
+                end = 3;
+                break;
+            }
+            // equiangular direction (:764-788): least_squares = inverse . 1, scaled by AA
+            double sw = 0.0;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) sw += slot_used(q) ? w[q] : 0.0;
+            sw = wave_sum(sw);
+            double AA = 1.0 / sqrt(sw);
+            if (!(fabs(AA) <= DBL_MAX)) AA = 1.0 / sqrt(fmax(sw, DBL_EPSILON));
+            double ls[Q];
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                ls[q] = slot_used(q) ? w[q] * AA : 0.0;
+                if (slot_used(q)) lsv[lane + 64 * q] = ls[q];
+            }
+            pass_fence();
+            // correlation of every atom with the direction (:800)
+            double corr[Q];
+#pragma unroll
+            for (int q = 0; q < Q; ++q) corr[q] = 0.0;
+#pragma unroll
+            for (int qi = 0; qi < Q; ++qi) {
+                unsigned long long m = used[qi];
+                while (m) {
+                    const int ii = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const int av = __builtin_amdgcn_readlane(act[qi], ii);
+                    const double li = lane_value(ls[qi], ii);
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) {
+                        const int j = lane + 64 * q;
+                        if (j < r) corr[q] += G[(size_t)av * r + j] * li;
+                    }
+                }
+            }
+            // step to the next atom that ties with the active ones, or to zero correlation (:806-808)
+            double t1 = DBL_MAX;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const int j = lane + 64 * q;
+                if (j < r && slot[q] < 0) {
+                    const double t = (C - cov[q]) / (AA - corr[q] + tiny32);
+                    if (t > 0.0 && t < t1) t1 = t;
+                }
+            }
+            double gamma = fmin(uni(wave_min(t1)), C / AA);
+            // ... or to the first active coefficient that reaches zero (:815-826)
+            double z[Q], lsj[Q], zmin = DBL_MAX;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                z[q] = 0.0;
+                lsj[q] = 0.0;
+                if (slot[q] >= 0) {
+                    lsj[q] = lsv[slot[q]];
+                    z[q] = -coef[q] / (lsj[q] + tiny32);
+                    if (z[q] > 0.0 && z[q] < zmin) zmin = z[q];
+                }
+            }
+            const double z_pos = uni(wave_min(zmin));
+            drop = false;
+            if (z_pos < gamma) {
+                gamma = z_pos;
+                drop = true;
+            }
+            ++n_iter;
+            prev_alpha = alpha;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                prev[q] = coef[q];
+                coef[q] = slot[q] >= 0 ? prev[q] + gamma * lsj[q] : 0.0;      // :847
+                if (slot[q] < 0) cov[q] -= gamma * corr[q];                   // :850
+            }
+            if (drop) {                                                        // :853-893
+                for (;;) {
+                    // lowest atom among those that reached zero in this event
+                    int cand = INT_MAX;
+#pragma unroll
+                    for (int q = Q - 1; q >= 0; --q)
+                        if (slot[q] >= 0 && z[q] == z_pos) cand = lane + 64 * q;
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) cand = min(cand, __shfl_xor(cand, off));
+                    const int v = uni(cand);
+                    if (v == INT_MAX) break;
+                    int kq = 0;
+#pragma unroll
+                    for (int q = 0; q < Q; ++q)
+                        if ((v >> 6) == q) kq = __builtin_amdgcn_readlane(slot[q], v & 63);
+                    const int k = kq;
+                    double p[Q];
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) p[q] = slot_used(q) ? P.at(k, lane + 64 * q) : 0.0;
+                    double pkk = 0.0;
+#pragma unroll
+                    for (int q = 0; q < Q; ++q)
+                        if ((k >> 6) == q) pkk = lane_value(p[q], k & 63);
+                    const double pinv = 1.0 / pkk;
+#pragma unroll
+                    for (int q = 0; q < Q; ++q)
+                        if ((k >> 6) == q) used[q] &= ~(1ull << (k & 63));
+                    pass_fence();
+                    // inverse of the remaining atoms: inverse -= p p^T / p_kk
+#pragma unroll
+                    for (int qi = 0; qi < Q; ++qi) {
+                        unsigned long long m = used[qi];
+                        while (m) {
+                            const int ii = __builtin_ctzll(m);
+                            m &= m - 1;
+                            const int i = 64 * qi + ii;
+                            const double pi = lane_value(p[qi], ii);
+#pragma unroll
+                            for (int q = 0; q < Q; ++q) {
+                                const int kk = lane + 64 * q;
+                                if (slot_used(q) && P.mine(i, kk)) P.at(i, kk) -= (pi * p[q]) * pinv;
+                            }
+                        }
+                    }
+                    // its correlation, recomputed from the data (:889)
+                    double dot = 0.0;
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) {
+                        const int j = lane + 64 * q;
+                        if (j < r) dot += G[(size_t)v * r + j] * coef[q];
+                    }
+                    dot = wave_sum(dot);
+#pragma unroll
+                    for (int q = 0; q < Q; ++q)
+                        if (lane + 64 * q == v) {
+                            cov[q] = xy[q] - dot;
+                            slot[q] = -1;
+                        }
+                    --n_active;
+                    ++n_drops;
+                    pass_fence();
+                }
+                pass_fence();
+                column_sums();
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int j = lane + 64 * q;
+            if (j < r) a.H[(size_t)j * a.ldh + col] = (float)coef[q];
+        }
+        if (a.info && lane == 0) {
+            int* rec = a.info + 4 * (size_t)col;
+            rec[0] = n_iter;
+            rec[1] = end;
+            rec[2] = n_active;
+            rec[3] = n_drops;
+        }
+        pass_fence();
+    }
+}
+
+LdsLimit g_lds_lars[8];
+
+template <int Q>
+int launch_lars_q(onmf_ctx* c, const LarsArgs& a0, hipStream_t s) {
+    LarsArgs a = a0;
+    const int r = a.r;
+    const size_t packed = (size_t)r * (r + 1) / 2;
+    const size_t ls_doubles = (size_t)((r + 1) & ~1);
+    const size_t lds_budget = 160 * 1024;
+    const size_t per_wave_lds = (ls_doubles + ((packed + 1) & ~(size_t)1)) * sizeof(double);
+    if (per_wave_lds <= lds_budget) {
+        int wpg = (int)(lds_budget / per_wave_lds);
+        if (wpg > 4) wpg = 4;
+        a.wave_doubles = (int)(per_wave_lds / sizeof(double));
+        a.Pws = nullptr;
+        a.p_stride = 0;
+        const size_t lds = per_wave_lds * wpg;
+        auto kern = lars_pos_kernel<Q, true>;
+        if (lds > 48 * 1024) ONMF_TRY(onmf_raise_lds_limit(c, g_lds_lars[Q - 1], (const void*)kern, lds));
+        const int grid = (a.b + wpg - 1) / wpg;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * wpg), lds, s, a);
+    } else {
+        // the inverse in global memory: a bounded number of waves, each with its own square
+        const int wpg = 4;
+        const size_t stride = (size_t)(64 * Q) * (64 * Q);
+        int waves = a.b < 1024 ? a.b : 1024;
+        const int grid = (waves + wpg - 1) / wpg;
+        ONMF_TRY(onmf_reserve(c, c->lars_ws, (size_t)grid * wpg * stride * sizeof(double), "LARS workspace"));
+        a.Pws = (double*)c->lars_ws.p;
+        a.p_stride = stride;
+        a.wave_doubles = (int)ls_doubles;
+        const size_t lds = ls_doubles * sizeof(double) * wpg;
+        hipLaunchKernelGGL((lars_pos_kernel<Q, false>), dim3(grid), dim3(64 * wpg), lds, s, a);
+    }
+    if (hipGetLastError() != hipSuccess) return onmf_fail(c, ONMF_ERR_HIP, "LARS coder: launch failed");
+    return ONMF_OK;
+}
+
+}  // namespace
+
+int launch_prod_f64(onmf_ctx* c, int M, int N, int K, const float* A, int lda, const float* B, int ldb, double* Out,
+                    int ldo, hipStream_t s) {
+    dim3 grid((N + PT - 1) / PT, (M + PT - 1) / PT);
+    hipLaunchKernelGGL(prod_f64_kernel, grid, dim3(256), 0, s, M, N, K, A, lda, B, ldb, Out, ldo);
+    if (hipGetLastError() != hipSuccess) return onmf_fail(c, ONMF_ERR_HIP, "double-precision product: launch failed");
+    return ONMF_OK;
+}
+
+int launch_lars_pos(onmf_ctx* c, int r, int b, const double* G, const double* Cd, int ldc, double alpha,
+                    double n_samples, int max_iter, float* H, int ldh, int* info, hipStream_t s) {
+    LarsArgs a{};
+    a.r = r;
+    a.b = b;
+    a.G = G;
+    a.Cd = Cd;
+    a.ldc = ldc;
+    a.alpha = alpha;
+    a.n_samples = n_samples;
+    a.max_iter = max_iter;
+    a.H = H;
+    a.ldh = ldh;
+    a.info = info;
+    if (r <= 64) return launch_lars_q<1>(c, a, s);
+    if (r <= 128) return launch_lars_q<2>(c, a, s);
+    if (r <= 192) return launch_lars_q<3>(c, a, s);
+    if (r <= 256) return launch_lars_q<4>(c, a, s);
+    return onmf_fail(c, ONMF_ERR_ARG, "LARS coder: r = %d > 256 is not supported", r);
+}

@@ -322,6 +322,20 @@ class Engine:
         _lib.check(rc, self.ctx, "onmf_sparse_code_each")
         return (H, sweeps) if want_sweeps else H
 
+    def sparse_code_lars(self, X, W, alpha=2.0, max_iter=1000, want_info=False):
+        """scikit-learn's positive LARS-lasso coder as src/ontf.py:79-86 calls it, one column per wavefront;
+        H (r x b).  ``want_info``: also an int32 (b, 4) tensor {events, end, active atoms, atoms dropped}."""
+        d, b = X.shape
+        r = W.shape[1]
+        if W.shape[0] != d:
+            raise ValueError("W has %d rows, X has %d" % (W.shape[0], d))
+        H = self.empty(r, b)
+        info = self.torch.empty(b, 4, dtype=self.torch.int32, device=self.device) if want_info else None
+        rc = self.lib.onmf_sparse_code_lars(self.ctx, d, r, b, _ptr(X), X.stride(0), _ptr(W), float(alpha),
+                                            int(max_iter), _ptr(H), _ptr(info), self.stream())
+        _lib.check(rc, self.ctx, "onmf_sparse_code_lars")
+        return (H, info) if want_info else H
+
     def patch_product(self, W, H):
         """W @ H (image_reconstruction.py:352, :385)."""
         d, r = W.shape

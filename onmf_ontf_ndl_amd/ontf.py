@@ -6,13 +6,16 @@ the steps of one call (src/ontf.py:236).  The code matrix of this class is (b x 
 onmf's (src/ontf.py:86, :147-148).
 
 The reference hands the sparse-code solve to scikit-learn (``SparseCoder``, lasso_lars, positive
-codes, alpha = ``self.alpha`` or 2; src/ontf.py:79-86).  Here the same convex problem
-    min_{h >= 0}  0.5 * ||x - W h||^2 + alpha * ||h||_1        (per column)
-is solved on the GPU by exact cyclic coordinate descent from h = 0: every column iterates until ITS
-relative change per sweep, ||h_new - h_old|| / ||h_old||, falls under ``cd_tol`` (at most
-``cd_max_sweeps`` sweeps) - the columns are independent problems, as they are for LARS - all in one
-kernel launch without host round trips.  It reaches the optimum that LARS approximates; it does not
-retrace the LARS path.
+codes, alpha = ``self.alpha`` or 2; src/ontf.py:79-86), i.e. per column the positive LARS-lasso path of
+    min_{h >= 0}  0.5 * ||x - W h||^2 + alpha * ||h||_1 .
+``coder="lars"`` (the default) follows that path on the GPU event by event, one column per wavefront
+(``onmf_sparse_code_lars``), including the way scikit-learn's routine ends it - short of the optimum
+once no atom with a positive correlation is left outside the active set - because the reference's
+aggregates, and so its dictionary, are built from exactly those codes.
+``coder="cd"`` solves the convex problem itself by exact cyclic coordinate descent from h = 0: every
+column iterates until ITS relative change per sweep, ||h_new - h_old|| / ||h_old||, falls under
+``cd_tol`` (at most ``cd_max_sweeps`` sweeps), all in one kernel launch without host round trips.  It
+reaches the optimum; it does not reproduce the reference's codes.
 """
 from __future__ import annotations
 
@@ -47,6 +50,8 @@ class Online_NTF():
                  rng="numpy",
                  seed=0,
                  device=None,
+                 coder="lars",
+                 lars_max_iter=1000,
                  cd_tol=1e-6,
                  cd_max_sweeps=4000):
         self.X = X
@@ -68,6 +73,10 @@ class Online_NTF():
         self.seed = seed
         self._device = device
         self._torch_io = _is_torch(X)
+        if coder not in ("lars", "cd"):
+            raise ValueError("coder must be 'lars' or 'cd'")
+        self.coder = coder
+        self.lars_max_iter = lars_max_iter          # SparseCoder's transform_max_iter (its default)
         self.cd_tol = cd_tol
         self.cd_max_sweeps = cd_max_sweeps
         self._sweeps_each = None
@@ -78,6 +87,10 @@ class Online_NTF():
     def _code_dev(self, eng, Xd, Wd):
         """Device solve; returns H as (r x b)."""
         a = 2 if self.alpha is None else self.alpha          # src/ontf.py:79-84
+        if self.coder == "lars":
+            if Wd.shape[1] > 256:
+                raise ValueError("coder='lars' supports n_components <= 256; use coder='cd'")
+            return eng.sparse_code_lars(Xd, Wd, alpha=a, max_iter=self.lars_max_iter)
         H0 = eng.zeros(Wd.shape[1], Xd.shape[1])
         H, sweeps = eng.sparse_code_each(Xd, Wd, H0=H0, alpha=a, sub_iter=self.cd_max_sweeps,
                                          stopping_diff=self.cd_tol, mode=_lib.CODER_EXACT_CD, want_sweeps=True)

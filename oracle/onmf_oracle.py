@@ -12,6 +12,9 @@ This module is a NumPy restatement of the hot path of HanbaekLyu/ONMF_ONTF_NDL:
 * ``unfold3`` / ``OracleOnlineNTF`` <- ``Online_NTF``           (src/ontf.py:19-244)
 * ``lasso_nonneg_code``      <- ``joint_sparse_code_tensor``    (src/ontf.py:59-89) which hands
                                the solve to scikit-learn's ``SparseCoder`` (LassoLars, positive)
+* ``lars_pos_path``          <- the routine behind that call: ``_lars_path_solver`` of scikit-learn
+                               1.7.2 (a dependency the reference neither vendors nor pins), restated
+                               branch by branch and pinned by vectors generated from the library
 
 Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may
 import it, and only as the checker / the timed CPU baseline.  The shipped GPU path never
@@ -40,7 +43,7 @@ import numpy as np
 __all__ = [
     "spectral_norm", "code_sweeps", "dictionary_pass", "aggregate_update", "minibatch_step",
     "OracleOnlineNMF", "unfold3", "lasso_nonneg_code", "lasso_objective", "OracleOnlineNTF",
-    "surrogate_loss",
+    "surrogate_loss", "lars_pos_path", "lars_pos_code",
 ]
 
 
@@ -251,10 +254,15 @@ def lasso_nonneg_code(X, W, alpha=None, solver="sklearn", sweeps=20000, tol=1e-1
 
     ``solver="sklearn"`` makes the call of src/ontf.py:79-86 verbatim in meaning
     (SparseCoder, lasso_lars, positive_code, transform_alpha = alpha or 2).
-    ``solver="cd"`` is an exact cyclic coordinate-descent restatement of the same convex
-    problem, run to a fixed point; the two agree to solver tolerance when W has full column rank.
+    ``solver="lars"`` is this module's own restatement of the path scikit-learn follows
+    (``lars_pos_code``): the same numbers as ``"sklearn"`` to rounding, without the library.
+    ``solver="cd"`` is exact cyclic coordinate descent on the same convex problem, run to a fixed
+    point - the optimum, which scikit-learn's positive path does NOT always reach (it misjudges the
+    last segment once no atom with a positive correlation is left outside the active set).
     """
     a = 2 if alpha is None else alpha
+    if solver == "lars":
+        return lars_pos_code(X, W, a)
     if solver == "sklearn":
         from sklearn.decomposition import SparseCoder
         coder = SparseCoder(dictionary=np.asarray(W).T, transform_n_nonzero_coefs=None,
@@ -276,6 +284,183 @@ def lasso_nonneg_code(X, W, alpha=None, solver="sklearn", sweeps=20000, tol=1e-1
         if biggest <= tol:
             break
     return H.T
+
+
+def _givens_delete(L, n, out):
+    """Remove row/column ``out`` from the n x n lower Cholesky factor held in L[:n, :n], in place.
+
+    Restates ``sklearn.utils.arrayfuncs.cholesky_delete`` (scikit-learn 1.7.2, arrayfuncs.pyx:86-117):
+    rows below ``out`` move up by one, then one Givens rotation per remaining row restores the
+    triangle (BLAS ``rotg`` sign convention: r takes the sign of the larger entry; a negative
+    diagonal is flipped together with c and s)."""
+    for i in range(out, n - 1):
+        L[i, :i + 2] = L[i + 1, :i + 2]
+    for i in range(out, n - 1):
+        a, b = L[i, i], L[i, i + 1]
+        roe = a if abs(a) > abs(b) else b
+        scale = abs(a) + abs(b)
+        if scale == 0.0:
+            c, s, rr = 1.0, 0.0, 0.0
+        else:
+            rr = scale * np.sqrt((a / scale) ** 2 + (b / scale) ** 2)
+            if roe < 0:
+                rr = -rr
+            c, s = a / rr, b / rr
+        if rr < 0:
+            rr, c, s = -rr, -c, -s
+        L[i, i], L[i, i + 1] = rr, 0.0
+        lo = L[i + 1:n - 1, i].copy()
+        hi = L[i + 1:n - 1, i + 1].copy()
+        L[i + 1:n - 1, i] = c * lo + s * hi
+        L[i + 1:n - 1, i + 1] = c * hi - s * lo
+
+
+def lars_pos_path(Gram, Xy, n_samples, alpha_min, max_iter=1000, eps=np.finfo(float).eps, info=None):
+    """Positive LARS-lasso path on a precomputed Gram matrix, ended at ``alpha_min``.
+
+    Restates ``sklearn.linear_model._least_angle._lars_path_solver`` (scikit-learn 1.7.2,
+    _least_angle.py:411-913) for the one argument set that src/ontf.py:79-86 reaches through
+    ``SparseCoder`` -> ``_sparse_encode_precomputed`` (_dict_learning.py:118-135) -> ``LassoLars.fit``
+    (_least_angle.py:1132-1149): method="lasso", positive=True, Gram and Xy given, return_path=False.
+    Every branch of that routine is kept, including the ones that end the path before alpha_min
+    (regressor limit, "alpha is increasing" bail-out) and the degenerate-pivot skip, because
+    they decide which coefficients the reference hands to its aggregate update.
+    ``info`` (a dict) receives n_iter, drops and the branch that ended the path."""
+    Gram = np.asarray(Gram, dtype=np.float64)
+    n_feat = Xy.shape[0]
+    Cov = np.array(Xy, dtype=np.float64)         # correlations of the inactive variables, in `rest` order
+    rest = list(range(n_feat))                   # inactive variables, aligned with Cov
+    active = []
+    coef = np.zeros(n_feat)
+    prev_coef = np.zeros(n_feat)
+    alpha = prev_alpha = 0.0
+    L = np.zeros((n_feat, n_feat))
+    n_iter = n_active = n_drops = 0
+    drop = False
+    tiny32 = np.finfo(np.float32).tiny
+    eq_tol = np.finfo(np.float32).eps
+    end = "?"
+    while True:
+        if Cov.size:
+            c_idx = int(np.argmax(Cov))
+            C = Cov[c_idx]
+        else:
+            C = 0.0
+        alpha = C / n_samples
+        if alpha <= alpha_min + eq_tol:                                  # :656-667
+            if abs(alpha - alpha_min) > eq_tol:
+                if n_iter > 0:
+                    ss = (prev_alpha - alpha_min) / (prev_alpha - alpha)
+                    coef = prev_coef + ss * (coef - prev_coef)
+                alpha = alpha_min
+            end = "alpha_min"
+            break
+        if n_iter >= max_iter or n_active >= n_feat:                     # :669-670
+            end = "full"
+            break
+        if not drop:                                                     # :671-741
+            new = rest[c_idx]
+            # the chosen variable trades places with the first inactive one (:687-690)
+            Cov[c_idx], Cov[0] = Cov[0], Cov[c_idx]
+            rest[c_idx], rest[0] = rest[0], rest[c_idx]
+            cov_full, rest_full = Cov, rest
+            Cov, rest = Cov[1:], rest[1:]
+            c = Gram[new, new]
+            L[n_active, :n_active] = Gram[new, active]
+            if n_active:
+                # forward substitution with the current factor (:705-713)
+                for i in range(n_active):
+                    L[n_active, i] = (L[n_active, i] - L[i, :i] @ L[n_active, :i]) / L[i, i]
+            v = L[n_active, :n_active] @ L[n_active, :n_active]
+            diag = max(np.sqrt(abs(c - v)), eps)
+            L[n_active, n_active] = diag
+            if diag < 1e-7:                                              # :719-738
+                Cov, rest = cov_full, rest_full
+                Cov[0] = 0
+                Cov[c_idx], Cov[0] = Cov[0], Cov[c_idx]
+                # the routine swaps the correlations back but leaves its index and Gram arrays swapped
+                # (`rest` here): position 0 keeps the old first variable's correlation under the
+                # skipped variable's name, position c_idx holds 0 under the old first one's
+                continue
+            active.append(new)
+            n_active += 1
+        if n_iter > 0 and prev_alpha < alpha:                            # :748-761
+            end = "alpha_up"
+            break
+        # direction: solve (L L^T) w = 1, scale to unit correlation decrease (:764-788)
+        ones = np.ones(n_active)
+        y = np.zeros(n_active)
+        for i in range(n_active):
+            y[i] = (ones[i] - L[i, :i] @ y[:i]) / L[i, i]
+        w = np.zeros(n_active)
+        for i in range(n_active - 1, -1, -1):
+            w[i] = (y[i] - L[i + 1:n_active, i] @ w[i + 1:n_active]) / L[i, i]
+        if n_active == 1 and w[0] == 0:
+            w[0] = 1.0
+            AA = 1.0
+        else:
+            AA = 1.0 / np.sqrt(np.sum(w))
+            if not np.isfinite(AA):
+                k = 0
+                while not np.isfinite(AA):
+                    Lr = L[:n_active, :n_active].copy()
+                    Lr.flat[::n_active + 1] += (2 ** k) * eps
+                    w = np.linalg.solve(Lr @ Lr.T, ones)
+                    AA = 1.0 / np.sqrt(max(np.sum(w), eps))
+                    k += 1
+            w = w * AA
+        corr = Gram[np.ix_(rest, active)] @ w if rest else np.zeros(0)   # :800
+        corr = np.around(corr, decimals=15)                              # :804
+        with np.errstate(divide="ignore", invalid="ignore"):
+            ratios = (C - Cov) / (AA - corr + tiny32)
+            pos = ratios[ratios > 0]
+            g1 = pos.min() if pos.size else np.finfo(np.float64).max
+            gamma = min(g1, C / AA)                                      # :806-808
+            z = -coef[active] / (w + tiny32)                             # :815
+        zp = z[z > 0]
+        z_pos = zp.min() if zp.size else np.finfo(np.float64).max
+        drop = False
+        if z_pos < gamma:
+            out = np.where(z == z_pos)[0][::-1]
+            gamma = z_pos
+            drop = True
+        n_iter += 1
+        prev_coef, prev_alpha = coef, alpha
+        coef = np.zeros(n_feat)
+        coef[active] = prev_coef[active] + gamma * w                     # :847
+        Cov = Cov - gamma * corr                                         # :850
+        if drop:                                                         # :853-893
+            for ii in out:
+                _givens_delete(L, n_active, int(ii))
+            n_active -= 1
+            gone = [active.pop(int(ii)) for ii in out]
+            temp = np.asarray(Xy, dtype=np.float64)[gone] - Gram[gone] @ coef
+            Cov = np.r_[temp, Cov]
+            rest = gone + rest
+            n_drops += len(gone)
+    if info is not None:
+        info.update(n_iter=n_iter, drops=n_drops, end=end, n_active=n_active, alpha=alpha)
+    return coef
+
+
+def lars_pos_code(X, W, alpha=None, info=None):
+    """Column-wise restatement of the coder call of src/ontf.py:79-86; returns H as (b x r).
+
+    scikit-learn scales the penalty by the number of features (_dict_learning.py:119) and the
+    path's alphas by the number of samples (_least_angle.py:655), both d here, so the path ends
+    where the largest correlation of an inactive atom reaches ``alpha`` itself."""
+    a = 2 if alpha is None else alpha
+    W = np.asarray(W, dtype=np.float64)
+    X = np.asarray(X, dtype=np.float64)
+    d = W.shape[0]
+    Gm, Cm = W.T @ W, W.T @ X
+    H = np.zeros((X.shape[1], W.shape[1]))
+    for c in range(X.shape[1]):
+        rec = {}
+        H[c] = lars_pos_path(Gm, Cm[:, c], d, float(a) / d, info=rec)
+        if info is not None:
+            info.append(rec)
+    return H
 
 
 class OracleOnlineNTF:

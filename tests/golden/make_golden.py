@@ -350,9 +350,61 @@ def g11_renoir():
     print("g11: sweeps", sweeps, "resid", resid)
 
 
+def _ntf_stream(shape, r, alpha, beta, batch, steps, seed):
+    """The loop of Online_NTF.train_dict_single (src/ontf.py:203-236) for mode 2 / learn_joint_dict, with the
+    reference's pieces that can be run here: scikit-learn's coder called with the arguments of src/ontf.py:79-86,
+    the aggregate lines of src/ontf.py:147-148 and the reference's own update_dict (src/onmf.py:92-116, the body
+    src/ontf.py:91-115 repeats).  src/ontf.py itself does not import here (tensorly, progressbar)."""
+    from sklearn.decomposition import SparseCoder
+    np.random.seed(seed)
+    T = np.random.rand(*shape)
+    Xu = np.reshape(np.moveaxis(T, 2, 0), (T.shape[2], -1)).T           # tl_unfold(T, 2).T, src/ontf.py:207
+    d, n = Xu.shape
+    W = np.random.rand(d, r)                                            # src/ontf.py:213
+    A, B = np.zeros((r, r)), np.zeros((r, d))
+    helper = Online_NMF(Xu, n_components=r)
+    out = dict(T=T, W0=W.copy())
+    for i in range(1, steps + 1):
+        idx = np.random.randint(n, size=batch)                          # src/ontf.py:230
+        X = Xu[:, idx]
+        coder = SparseCoder(dictionary=W.T, transform_n_nonzero_coefs=None,
+                            transform_alpha=2 if alpha is None else alpha,
+                            transform_algorithm="lasso_lars", positive_code=True)
+        H = coder.transform(X.T)
+        t = np.float64(i)
+        wt = t ** (-(1 if beta is None else beta))
+        A1 = (1 - wt) * A + wt * np.dot(H.T, H)
+        B1 = (1 - wt) * B + wt * np.dot(H.T, X.T)
+        W = helper.update_dict(W, A, B)                                 # old aggregates, src/ontf.py:151
+        A, B = A1, B1
+        out.update({"idx_%d" % i: idx, "H_%d" % i: H, "A_%d" % i: A, "B_%d" % i: B, "W_%d" % i: W})
+    return out
+
+
+def g12_ntf_lars():
+    """Online_NTF streams coded by scikit-learn's positive LassoLars (src/ontf.py:79-86, :136-151), and the coder
+    alone at the C3 shape (d = 1200, r = 100, b = 100; inputs are float32 values drawn from RandomState(29),
+    redrawn by the tests, only the codes are stored)."""
+    from sklearn.decomposition import SparseCoder
+    a = _ntf_stream((16, 3, 200), 8, 0.5, None, 40, 6, 27)
+    save("g12_ntf_a", alpha=np.float64(0.5), steps=np.int64(6), **a)
+    bq = _ntf_stream((25, 3, 300), 12, None, 0.7, 64, 7, 28)
+    save("g12_ntf_b", steps=np.int64(7), beta=np.float64(0.7), **bq)
+    rs = np.random.RandomState(29)
+    d, r, b = 1200, 100, 100
+    X = rs.rand(d, b).astype(np.float32).astype(np.float64)
+    W = rs.rand(d, r).astype(np.float32).astype(np.float64) / 32       # exact scaling; column norms ~ 0.62
+    out = {}
+    for name, alpha in (("a2", 2), ("a01", 0.1)):
+        coder = SparseCoder(dictionary=W.T, transform_n_nonzero_coefs=None, transform_alpha=alpha,
+                            transform_algorithm="lasso_lars", positive_code=True)
+        out["H_" + name] = coder.transform(X.T)
+    save("g12_ntf_c3", **out)
+
+
 if __name__ == "__main__":
     cases = (g1_code, g2_dict, g3_steps, g4_train_warm, g5_subsample, g6_full_code,
-             g7_beta_alpha, g8_stream, g9_lasso, g10_image, g11_renoir)
+             g7_beta_alpha, g8_stream, g9_lasso, g10_image, g11_renoir, g12_ntf_lars)
     want = set(sys.argv[1:])
     for fn in cases:
         if not want or fn.__name__.split("_")[0] in want:

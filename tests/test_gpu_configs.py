@@ -211,7 +211,7 @@ def test_c3_ntf_step_against_oracle_cd(eng, orc):
     assert X.shape == (d, b)
     W, A, B = warm_state(rs, d, r)
     H_o, A_o, B_o, W_o = ref.step(X, A.astype(np.float64), B.astype(np.float64), W.astype(np.float64), 7)
-    ntf = Online_NTF(T, n_components=r, mode=2, learn_joint_dict=True, alpha=0.5, cd_tol=0.0,
+    ntf = Online_NTF(T, n_components=r, mode=2, learn_joint_dict=True, alpha=0.5, coder="cd", cd_tol=0.0,
                      cd_max_sweeps=SWEEPS)
     H, A1, B1, W1 = ntf.step(X, A, B, W, np.int64(7))
     assert H.shape == (b, r) and ntf.last_sweeps == SWEEPS
@@ -222,7 +222,7 @@ def test_c3_ntf_step_against_oracle_cd(eng, orc):
 
 
 def test_c3_ntf_batch_2048_against_sklearn_and_oracle(eng, orc):
-    """b = 2048 columns in one launch, default settings (alpha = 2, the library's own stopping rule).
+    """The coordinate-descent coder (coder="cd"): b = 2048 columns in one launch, alpha = 2, its own stopping rule.
     A 64-column slice is solved by scikit-learn with the reference's arguments (src/ontf.py:79-86): the
     GPU's objective is never above scikit-learn's.  The same slice sweep for sweep against the oracle's
     coordinate descent; and columns are independent: the slice coded alone gives the same codes."""
@@ -230,7 +230,7 @@ def test_c3_ntf_batch_2048_against_sklearn_and_oracle(eng, orc):
     d, r, b = 1200, 100, 2048
     rs = np.random.RandomState(32)
     T = patch_tensor(rs, b)
-    ntf = Online_NTF(T, n_components=r, mode=2, learn_joint_dict=True, alpha=None)    # alpha = 2
+    ntf = Online_NTF(T, n_components=r, mode=2, learn_joint_dict=True, alpha=None, coder="cd")    # alpha = 2
     X = host(ntf.unfold())
     W, _, _ = warm_state(rs, d, r)
     H = ntf.joint_sparse_code_tensor(X, W)
@@ -243,7 +243,7 @@ def test_c3_ntf_batch_2048_against_sklearn_and_oracle(eng, orc):
     assert np.all(f_gpu <= f_sk * (1 + 1e-5) + 1e-7)
     H_alone = ntf.joint_sparse_code_tensor(Xs, W)
     assert relerr(H_alone, H[sl]) < 1e-4
-    fixed = Online_NTF(T, n_components=r, mode=2, learn_joint_dict=True, alpha=None, cd_tol=0.0,
+    fixed = Online_NTF(T, n_components=r, mode=2, learn_joint_dict=True, alpha=None, coder="cd", cd_tol=0.0,
                        cd_max_sweeps=SWEEPS)
     H_fix = fixed.joint_sparse_code_tensor(X, W)
     H_cd = orc.lasso_nonneg_code(Xs, Ws, None, solver="cd", sweeps=SWEEPS, tol=-1.0)
@@ -251,7 +251,7 @@ def test_c3_ntf_batch_2048_against_sklearn_and_oracle(eng, orc):
 
 
 def test_c3_ntf_train_dict_single_against_oracle(eng, orc):
-    """train_dict_single on a (400, 3, 300) tensor, mode 2 / joint (d=1200), r=100, 3 steps of 100
+    """(coder="cd") train_dict_single on a (400, 3, 300) tensor, mode 2 / joint (d=1200), r=100, 3 steps of 100
     subsampled columns with carried aggregates (src/ontf.py:224-236), same NumPy random stream as the
     oracle class, the coder sweep for sweep on both sides."""
     from onmf_ontf_ndl_amd import Online_NTF
@@ -261,7 +261,7 @@ def test_c3_ntf_train_dict_single_against_oracle(eng, orc):
     kw = dict(n_components=r, iterations=4, batch_size=100, mode=2, learn_joint_dict=True, alpha=1.0,
               subsample=True)
     np.random.seed(8)
-    W, A, B, code = Online_NTF(T, cd_tol=0.0, cd_max_sweeps=SWEEPS, **kw).train_dict_single()
+    W, A, B, code = Online_NTF(T, coder="cd", cd_tol=0.0, cd_max_sweeps=SWEEPS, **kw).train_dict_single()
     np.random.seed(8)
     W_o, A_o, B_o, _ = orc.OracleOnlineNTF(T.astype(np.float64), solver="cd", cd_sweeps=SWEEPS, cd_tol=-1.0,
                                            **kw).train_dict_single()
@@ -271,6 +271,41 @@ def test_c3_ntf_train_dict_single_against_oracle(eng, orc):
     assert relerr(W, W_o) < TOL_W
     # (three chained steps of 300 coordinate-descent sweeps each on carried state)
     assert relerr(A, A_o) < 1e-4 and relerr(B, B_o) < 1e-4
+
+
+def test_c3_ntf_lars_against_sklearn(eng, orc):
+    """The default coder at the C3 size: 320 columns (d = 1200, r = 100) of a patch tensor coded on the GPU and by
+    scikit-learn called with the reference's arguments (src/ontf.py:79-86), for a dense random dictionary
+    (first steps of a stream: 60-80 active atoms per column) and after a dictionary pass on warm aggregates;
+    then one whole Online_NTF.step against the oracle's step driven by scikit-learn."""
+    from onmf_ontf_ndl_amd import Online_NTF
+    d, r, b = 1200, 100, 320
+    rs = np.random.RandomState(34)
+    T = patch_tensor(rs, b)
+    ntf = Online_NTF(T, n_components=r, mode=2, learn_joint_dict=True, alpha=None)    # alpha = 2, coder = "lars"
+    X = host(ntf.unfold())
+    W, A, B = warm_state(rs, d, r)
+    worst = 0.0
+    for name, Wk, alpha in (("warm", W, None), ("dense", rs.rand(d, r).astype(np.float32), 0.3)):
+        ntf.alpha = alpha
+        H, info = eng.sparse_code_lars(eng.dev(X), eng.dev(Wk), alpha=2 if alpha is None else alpha, want_info=True)
+        H = host(H).T
+        info = info.cpu().numpy()
+        H_sk = orc.lasso_nonneg_code(X, Wk.astype(np.float64), alpha, solver="sklearn")
+        err = relerr(H, H_sk)
+        report("c3 lars coder vs scikit-learn (%s dictionary)" % name, H=err, max_abs=float(np.abs(H - H_sk).max()),
+               events_mean=float(info[:, 0].mean()), events_max=int(info[:, 0].max()),
+               active_mean=float(info[:, 2].mean()), dropped=int(info[:, 3].sum()),
+               ended_at_alpha=int((info[:, 1] == 1).sum()))
+        assert H.shape == (b, r) and H.min() >= 0
+        assert err < 1e-4
+        worst = max(worst, err)
+    ntf.alpha = None
+    ref = orc.OracleOnlineNTF(T, n_components=r, mode=2, learn_joint_dict=True, alpha=None, solver="sklearn")
+    H_o, A_o, B_o, W_o = ref.step(X, A.astype(np.float64), B.astype(np.float64), W.astype(np.float64), 7)
+    H1, A1, B1, W1 = ntf.step(X, A, B, W, np.int64(7))
+    report("c3 lars step vs oracle(sklearn)", H=relerr(H1, H_o), A=relerr(A1, A_o), B=relerr(B1, B_o), W=relerr(W1, W_o))
+    assert relerr(H1, H_o) < 1e-4 and relerr(A1, A_o) < 1e-4 and relerr(B1, B_o) < 1e-4 and relerr(W1, W_o) < TOL_W
 
 
 def test_exact_cd_in_chunks(eng, orc):

@@ -219,3 +219,71 @@ def test_unfold3_shapes_and_layout():
     np.testing.assert_array_equal(orc.unfold3(T, 0), T.reshape(4, 15))
     np.testing.assert_array_equal(orc.unfold3(T, 2)[1], T[:, :, 1].reshape(-1))
     np.testing.assert_array_equal(orc.unfold3(T, 1)[2], T[:, 2, :].reshape(-1))
+
+
+# ----------------------------------------------------------------------------------------
+# scikit-learn's positive LARS path (the coder of src/ontf.py:79-86), restated
+# ----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,alpha", [("default2", None), ("a05", 0.5), ("a005", 0.05)])
+def test_g9_lars_restatement_matches_sklearn_vectors(name, alpha):
+    g = load_golden("g9_lasso")
+    info = []
+    H = orc.lars_pos_code(g["X"], g["W"], alpha, info=info)
+    assert relerr(H, g["H_" + name]) < TOL
+    assert all(i["end"] == "alpha_min" for i in info)
+    # ... and it is NOT the optimum of the convex problem where the path ran out of positive correlations
+    if alpha == 0.05:
+        cd = orc.lasso_nonneg_code(g["X"], g["W"], alpha, solver="cd")
+        assert np.abs(cd - H).max() > 1e-3
+
+
+def _unfold_joint(T):
+    return np.reshape(np.moveaxis(T, 2, 0), (T.shape[2], -1)).T
+
+
+@pytest.mark.parametrize("case,r,alpha,beta,batch,seed", [("g12_ntf_a", 8, 0.5, None, 40, 27),
+                                                          ("g12_ntf_b", 12, None, 0.7, 64, 28)])
+def test_g12_ntf_streams_coded_by_sklearn(case, r, alpha, beta, batch, seed):
+    """OracleOnlineNTF with the restated path (solver="lars") reproduces, from NumPy's global stream alone,
+    the streams that scikit-learn's coder and the reference's update_dict produced."""
+    g = load_golden(case)
+    steps = int(g["steps"])
+    np.random.seed(seed)
+    T = np.random.rand(*g["T"].shape)
+    assert np.array_equal(T, g["T"])
+    ntf = orc.OracleOnlineNTF(T, n_components=r, iterations=steps + 1, batch_size=batch, mode=2,
+                              learn_joint_dict=True, alpha=alpha, beta=beta, subsample=True, solver="lars")
+    W, A, B, _ = ntf.train_dict_single()
+    assert relerr(W, g["W_%d" % steps]) < 1e-10
+    assert relerr(A, g["A_%d" % steps]) < 1e-10 and relerr(B, g["B_%d" % steps]) < 1e-10
+    assert ntf.history == steps + 1
+    # one step alone on stored inputs, codes included
+    Xu = _unfold_joint(T)
+    i = steps
+    H, A1, B1, W1 = ntf.step(Xu[:, g["idx_%d" % i]], g["A_%d" % (i - 1)], g["B_%d" % (i - 1)], g["W_%d" % (i - 1)],
+                             np.float64(i))
+    assert relerr(H, g["H_%d" % i]) < 1e-10 and relerr(W1, g["W_%d" % i]) < TOL
+
+
+def test_g12_cd_optimum_is_not_the_references_dictionary():
+    """What following the path buys: the same stream coded to the optimum of the convex problem ends with a
+    dictionary 1e-3 away from the one the reference's coder leads to."""
+    g = load_golden("g12_ntf_a")
+    np.random.seed(27)
+    T = np.random.rand(*g["T"].shape)
+    ntf = orc.OracleOnlineNTF(T, n_components=8, iterations=7, batch_size=40, mode=2, learn_joint_dict=True,
+                              alpha=0.5, subsample=True, solver="cd")
+    W, _, _, _ = ntf.train_dict_single()
+    assert relerr(W, g["W_6"]) > 1e-3
+
+
+def test_g12_lars_restatement_at_c3_shape():
+    g = load_golden("g12_ntf_c3")
+    rs = np.random.RandomState(29)
+    d, r, b = 1200, 100, 100
+    X = rs.rand(d, b).astype(np.float32).astype(np.float64)
+    W = rs.rand(d, r).astype(np.float32).astype(np.float64) / 32
+    cols = slice(0, 24)                      # pure-Python path: a slice keeps the CPU suite short
+    for name, alpha in (("a2", 2), ("a01", 0.1)):
+        H = orc.lars_pos_code(X[:, cols], W, alpha)
+        assert relerr(H, g["H_" + name][cols]) < 1e-10
