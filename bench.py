@@ -172,6 +172,9 @@ def parse_args(argv=None):
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
                     help="library option (ONMF_OPT_* number = value), for experiments")
     ap.add_argument("--cpu-cols", type=int, default=0, help="columns of the CPU-baseline sample (0 = auto)")
+    ap.add_argument("--coder", default="lars", choices=["lars", "cd"],
+                    help="c3-ntf workloads: scikit-learn's positive LARS path (the reference's coder) or exact "
+                         "coordinate descent on the same convex problem")
     return ap.parse_args(argv)
 
 
@@ -246,7 +249,7 @@ def main():
     coder = None
     if ntf:
         from onmf_ontf_ndl_amd import Online_NTF
-        coder = Online_NTF(torch.zeros(2, 3, 4), n_components=r, alpha=None, device=eng.device)
+        coder = Online_NTF(torch.zeros(2, 3, 4), n_components=r, alpha=None, device=eng.device, coder=args.coder)
 
     def one_step(i):
         nonlocal cur, t
@@ -297,10 +300,19 @@ def main():
         value = world * b * args.steps / elapsed
         mean_sweeps = float(np.mean(sweeps_seen)) if sweeps_seen else 0.0
         if ntf:
-            desc = ("%s: Online_NTF.step, d=%d r=%d batch=%d per GPU, lasso coder alpha=2 by coordinate descent "
-                    "(cd_tol=%g, at most %d sweeps per column), (A,B,W) carried"
-                    % (args.workload, d, r, b, coder.cd_tol, coder.cd_max_sweeps))
-            cfg = {"workload": desc, "sweeps_slowest_column_last_step": coder.last_sweeps}
+            if args.coder == "lars":
+                desc = ("%s: Online_NTF.step, d=%d r=%d batch=%d per GPU, lasso coder alpha=2: scikit-learn's positive "
+                        "LARS path per column (the reference's coder), (A,B,W) carried" % (args.workload, d, r, b))
+                _, info = eng.sparse_code_lars(Xs[0], state[cur].W, alpha=2.0, want_info=True)
+                info = info.cpu().numpy()
+                cfg = {"workload": desc, "lars_events_per_column_mean": float(info[:, 0].mean()),
+                       "lars_events_per_column_max": int(info[:, 0].max()),
+                       "lars_active_atoms_mean": float(info[:, 2].mean())}
+            else:
+                desc = ("%s: Online_NTF.step, d=%d r=%d batch=%d per GPU, lasso coder alpha=2 by coordinate descent "
+                        "(cd_tol=%g, at most %d sweeps per column), (A,B,W) carried"
+                        % (args.workload, d, r, b, coder.cd_tol, coder.cd_max_sweeps))
+                cfg = {"workload": desc, "sweeps_slowest_column_last_step": coder.last_sweeps}
         else:
             flops = step_flops(d, r, b, mean_sweeps)
             cfg = {"workload": "%s: d=%d r=%d batch=%d per GPU, alpha=0 beta=1 sub_iter=%d "

@@ -9,8 +9,8 @@ Same constructor arguments and method names as the reference (image_reconstructi
   gather kernel instead of ``np.append`` in a loop;
 * ``train_dict(mode, learn_joint_dict)`` (:220-262)  the warm-restarted ``Online_NTF`` chain;
 * ``reconstruct_image`` (:269-285), ``reconstruct_image_color`` (:287-328)  the per-window LassoLars
-  solves (positive codes, alpha = 1) as ONE batched solve of the same convex problem - windows are
-  independent columns - then product and overlap average on the GPU.
+  solves (positive codes, alpha = 1) as ONE batched launch of the same path, one window per wavefront
+  (``Online_NTF``'s default coder) - then product and overlap average on the GPU.
 """
 from __future__ import annotations
 

@@ -217,12 +217,15 @@ class Network_Reconstructor():
         self.emb = emb
         return self.W
 
-    def reconstruct_network(self, recons_iter=100, *, return_weights=False, cd_tol=1e-6, cd_max_sweeps=4000):
-        """``recons_iter`` chain steps; every patch is coded against the dictionary (positive lasso with
-        alpha = 0, i.e. non-negative least squares - the reference's LassoLars call), reconstructed and
-        averaged onto the ordered node pairs its embedding covers; pairs whose mean rounds to 1 become the
-        edges of the result (network_reconstruction_nx.py:444-511).  All patches are coded in one batched
-        solve and accumulated by one kernel into dense n x n sums.  Returns a ``networkx.Graph`` when
+    def reconstruct_network(self, recons_iter=100, *, return_weights=False, coder="lars", cd_tol=1e-6,
+                            cd_max_sweeps=4000):
+        """``recons_iter`` chain steps; every patch is coded against the dictionary (the reference's call:
+        scikit-learn's positive LassoLars with transform_alpha = 0, network_reconstruction_nx.py:466-473),
+        reconstructed and averaged onto the ordered node pairs its embedding covers; pairs whose mean rounds
+        to 1 become the edges of the result (network_reconstruction_nx.py:444-511).  All patches are coded in
+        one batched solve - ``coder="lars"``: the library's path followed event by event (the reference's
+        codes); ``coder="cd"``: the non-negative least-squares problem itself by coordinate descent - and
+        accumulated by one kernel into dense n x n sums.  Returns a ``networkx.Graph`` when
         networkx is importable, else an (m, 2) array of node-label pairs; ``return_weights`` adds the
         (n x n) mean and count matrices (node order = ``self.nodes``)."""
         eng = self._engine()
@@ -235,10 +238,15 @@ class Network_Reconstructor():
                                           seed=self.seed, step_offset=self._next_steps(recons_iter), want_trace=True)
         Wd = eng.dev(self.W)
         from . import _lib
-        H0 = eng.zeros(Wd.shape[1], X.shape[1])
-        # every patch is its own least-squares problem: one launch, each column with its own stopping test
-        H = eng.sparse_code_each(X, Wd, H0=H0, alpha=0.0, sub_iter=cd_max_sweeps, stopping_diff=cd_tol,
-                                 mode=_lib.CODER_EXACT_CD)
+        if coder == "lars" and Wd.shape[1] <= 256:
+            H = eng.sparse_code_lars(X, Wd, alpha=0.0)
+        elif coder in ("lars", "cd"):
+            H0 = eng.zeros(Wd.shape[1], X.shape[1])
+            # every patch is its own least-squares problem: one launch, each column with its own stopping test
+            H = eng.sparse_code_each(X, Wd, H0=H0, alpha=0.0, sub_iter=cd_max_sweeps, stopping_diff=cd_tol,
+                                     mode=_lib.CODER_EXACT_CD)
+        else:
+            raise ValueError("coder must be 'lars' or 'cd'")
         total, count = eng.ndl_accumulate_edges(n, trace, eng.patch_product(Wd, H))
         mean = eng.torch.where(count > 0, total / count.clamp(min=1), eng.torch.zeros_like(total))
         keep = eng.torch.round(mean) > 0                       # np.round: exactly 0.5 goes to 0

