@@ -335,6 +335,13 @@ double onmf_host_lambda_max(const float* S_host, int n);
  *                          the sweeps continued from there) so that the host is not in the loop; 0
  *                          (default: the kernel does not yet beat the host's round trip): the host
  *                          evaluates every inconclusive test.  Same sweep counts and codes either way.
+ *   ONMF_OPT_LARS_SLOTS    onmf_sparse_code_lars keeps, per column, the inverse Gram matrix of the active atoms in
+ *                          LDS.  Room for all r atoms lets only a few wavefronts be resident per CU, so a call
+ *                          sizes its launch by the most atoms any column of the PREVIOUS call held at a time
+ *                          (plus a quarter; 16, 32, 48 or 64 slots) and codes the columns that need more in a
+ *                          second launch with room for r (ONMF_CNT_LARS_RECODED counts them).  0 (default):
+ *                          that rule; n > 0: n slots (at most 64, or r) in the first launch whatever the
+ *                          history.  Same codes either way.
  *   ONMF_OPT_SPIN_LIMIT_MS bound, in milliseconds, of the waits of workgroups for each other - a
  *                          one-launch solve's, and the dictionary pass's for d > 1024 (default 2000;
  *                          -1: give up at the first look if what is waited for is not there yet; -2: give
@@ -355,6 +362,7 @@ double onmf_host_lambda_max(const float* S_host, int n);
 #define ONMF_OPT_PERSISTENT_SWEEPS 7
 #define ONMF_OPT_SPIN_LIMIT_MS 8
 #define ONMF_OPT_DEVICE_RESOLVE 9
+#define ONMF_OPT_LARS_SLOTS 10
 int onmf_set_option(onmf_ctx* ctx, int key, int value);
 /*
  * Event counters since onmf_create (no counterpart in the reference):
@@ -367,6 +375,10 @@ int onmf_set_option(onmf_ctx* ctx, int key, int value);
 #define ONMF_CNT_DICT_TIMEOUTS 2
 #define ONMF_CNT_FALLBACK_SOLVES 3
 #define ONMF_CNT_DEVICE_RESOLVES 4   /* inconclusive stopping tests settled on the device (no host round trip) */
+#define ONMF_CNT_LARS_RECODED 5      /* columns of onmf_sparse_code_lars coded by its second launch (calls still in
+                                        flight are not in the count yet) */
+#define ONMF_CNT_LARS_SLOTS_USED 6   /* not a count: the most atoms a column of the last completed
+                                        onmf_sparse_code_lars call held at a time */
 int onmf_get_counter(onmf_ctx* ctx, int which, long long* value);
 /* Summed device time (ms) and number of sweep-kernel launches since the previous call. */
 int onmf_get_profile(onmf_ctx* ctx, double* sweep_ms, int* sweep_launches);

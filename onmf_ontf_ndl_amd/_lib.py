@@ -24,10 +24,13 @@ OPT_DICT_KERNEL = 6
 OPT_PERSISTENT_SWEEPS = 7
 OPT_SPIN_LIMIT_MS = 8
 OPT_DEVICE_RESOLVE = 9
+OPT_LARS_SLOTS = 10
 CNT_SWEEP_TIMEOUTS = 1
 CNT_DICT_TIMEOUTS = 2
 CNT_FALLBACK_SOLVES = 3
 CNT_DEVICE_RESOLVES = 4
+CNT_LARS_RECODED = 5
+CNT_LARS_SLOTS_USED = 6
 NDL_GLAUBER = 0
 NDL_PIVOT = 1
 

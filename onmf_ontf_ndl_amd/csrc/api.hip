@@ -148,7 +148,7 @@ int onmf_destroy(onmf_ctx* c) {
     (void)hipDeviceSynchronize();
     DevBuf* bufs[] = {&c->slab, &c->cm, &c->gram, &c->hbuf[0], &c->hbuf[1], &c->stats, &c->small,
                       &c->qt, &c->sync, &c->idx, &c->dbuf, &c->slab_side, &c->screen, &c->ddelta, &c->slab_prep,
-                      &c->gstack, &c->rslab, &c->gram64, &c->cm64, &c->lars_ws};
+                      &c->gstack, &c->rslab, &c->gram64, &c->cm64, &c->lars_ws, &c->lars_meta, &c->lars_overflow};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (c->pinned) (void)hipHostFree(c->pinned);
@@ -182,6 +182,7 @@ int onmf_set_option(onmf_ctx* c, int key, int value) {
             c->persistent_hold = 0;
             return ONMF_OK;
         case ONMF_OPT_DEVICE_RESOLVE: c->device_resolve = value; return ONMF_OK;
+        case ONMF_OPT_LARS_SLOTS: c->lars_slots = value < 0 ? 0 : value; return ONMF_OK;
         case ONMF_OPT_SPIN_LIMIT_MS:
             c->spin_limit = value == -2 ? SPIN_FORCE_TIMEOUT
                                         : value < 0 ? -1LL : (long long)value * 100000LL;      // 100 MHz ticks
@@ -201,6 +202,12 @@ int onmf_get_counter(onmf_ctx* c, int which, long long* value) {
             return ONMF_OK;
         case ONMF_CNT_FALLBACK_SOLVES: *value = c->n_fallback_solves; return ONMF_OK;
         case ONMF_CNT_DEVICE_RESOLVES: *value = c->n_device_resolves; return ONMF_OK;
+        case ONMF_CNT_LARS_RECODED:
+            *value = c->host_events ? ((volatile int*)c->host_events)[ONMF_LARS_HOST_WORDS + 2] : 0;
+            return ONMF_OK;
+        case ONMF_CNT_LARS_SLOTS_USED:
+            *value = c->host_events ? ((volatile int*)c->host_events)[ONMF_LARS_HOST_WORDS] : 0;
+            return ONMF_OK;
         default: return onmf_fail(c, ONMF_ERR_ARG, "onmf_get_counter: unknown counter %d", which);
     }
 }

@@ -81,7 +81,9 @@ struct onmf_ctx {
     long long n_fallback_solves = 0;      // solves run with one launch per sweep because of an earlier timeout
     float* static_scratch = nullptr;      // this device's copy of the library's static scratch array
     // positive-LARS coder: W^T W and W^T X accumulated in double, per-wave inverses that do not fit in LDS
-    DevBuf gram64, cm64, lars_ws;
+    DevBuf gram64, cm64, lars_ws, lars_meta, lars_overflow;
+    bool lars_hint_ok = false;            // a LARS call of this context has published its slot count
+    int lars_slots = 0;                   // ONMF_OPT_LARS_SLOTS
 };
 
 // Makes the context's device current for the duration of an entry point and puts the caller's back
@@ -231,6 +233,8 @@ int launch_ndl_edge_accumulate(int n, int k, int T, const int* emb_trace, const 
                                float* count, hipStream_t s);
 
 // Stopping-test screen: state layout and kernels.
+// words of onmf_ctx::host_events that the LARS coder's last kernel writes: slots used, r, columns recoded
+constexpr int ONMF_LARS_HOST_WORDS = 4;
 constexpr int SCREEN_MAX_SWEEPS = 64;
 constexpr int SCREEN_REPL = 8;       // replicas of the sweep kernel's accumulators (atomic contention)
 constexpr int SCREEN_ZREPL = 4;      // replicas of the power-step accumulator

@@ -93,30 +93,21 @@ __global__ __launch_bounds__(256) void prod_f64_kernel(int M, int N, int K, cons
 }
 
 // ---------------------------------------------------------------------------------------------
-// wave-wide helpers on doubles (butterflies: every lane ends with the same bits)
+// wave-wide helpers on doubles.  Rows of 16 lanes are reduced with DPP rotations (no LDS crossbar), the
+// four row results are fetched with v_readlane; every lane (and the scalar unit) ends with the same bits.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    return v;
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double wave_min(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off));
-    return v;
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false);
 }
-// largest value, lowest index among equals
-__device__ __forceinline__ void wave_argmax(double& v, int& idx) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const double ov = __shfl_xor(v, off);
-        const int oi = __shfl_xor(idx, off);
-        if (ov > v || (ov == v && oi < idx)) {
-            v = ov;
-            idx = oi;
-        }
-    }
-}
+constexpr int ROR1 = 0x121, ROR2 = 0x122, ROR4 = 0x124, ROR8 = 0x128;      // row_ror:n
+
 __device__ __forceinline__ double lane_value(double v, int l) {       // l wave-uniform
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
@@ -126,6 +117,47 @@ __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlan
 __device__ __forceinline__ double uni(double v) {
     return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)),
                             __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+__device__ __forceinline__ double wave_sum(double v) {
+    v += dpp_f64<ROR1>(v);
+    v += dpp_f64<ROR2>(v);
+    v += dpp_f64<ROR4>(v);
+    v += dpp_f64<ROR8>(v);
+    return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
+}
+__device__ __forceinline__ double wave_min(double v) {
+    v = fmin(v, dpp_f64<ROR1>(v));
+    v = fmin(v, dpp_f64<ROR2>(v));
+    v = fmin(v, dpp_f64<ROR4>(v));
+    v = fmin(v, dpp_f64<ROR8>(v));
+    return fmin(fmin(lane_value(v, 0), lane_value(v, 16)), fmin(lane_value(v, 32), lane_value(v, 48)));
+}
+__device__ __forceinline__ int wave_min(int v) {
+    v = min(v, dpp_i32<ROR1>(v));
+    v = min(v, dpp_i32<ROR2>(v));
+    v = min(v, dpp_i32<ROR4>(v));
+    v = min(v, dpp_i32<ROR8>(v));
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+// largest value, lowest index among equals
+__device__ __forceinline__ void take_better(double& v, int& idx, double ov, int oi) {
+    if (ov > v || (ov == v && oi < idx)) {
+        v = ov;
+        idx = oi;
+    }
+}
+__device__ __forceinline__ void wave_argmax(double& v, int& idx) {
+    take_better(v, idx, dpp_f64<ROR1>(v), dpp_i32<ROR1>(idx));
+    take_better(v, idx, dpp_f64<ROR2>(v), dpp_i32<ROR2>(idx));
+    take_better(v, idx, dpp_f64<ROR4>(v), dpp_i32<ROR4>(idx));
+    take_better(v, idx, dpp_f64<ROR8>(v), dpp_i32<ROR8>(idx));
+    double bv = lane_value(v, 0);
+    int bi = __builtin_amdgcn_readlane(idx, 0);
+#pragma unroll
+    for (int l = 16; l < 64; l += 16) take_better(bv, bi, lane_value(v, l), __builtin_amdgcn_readlane(idx, l));
+    v = bv;
+    idx = bi;
 }
 // what one pass over the inverse wrote must be visible to the next pass's lanes (same wave)
 __device__ __forceinline__ void pass_fence() {
@@ -144,14 +176,21 @@ struct LarsArgs {
     float* H;               // r x ldh out
     int ldh;
     int* info;              // nullable: per column {events, how the path ended (1 alpha reached, 2 all atoms
-                            // active or event limit, 3 alpha went up), active atoms, atoms dropped}
+                            // active or event limit, 3 alpha went up, 4 safety limit), active atoms, atoms dropped}
     double* Pws;            // global workspace of the inverse (P_LDS == false), p_stride doubles per wave
     size_t p_stride;
     int wave_doubles;       // LDS doubles per wave
+    int n_cap;              // slots of the inverse (active atoms a column can hold at a time)
+    // meta[0]: columns that needed more than n_cap slots (their indices go to `overflow`; a second launch
+    // with room for every atom codes them), meta[1]: most slots any column of the call used
+    int* meta;
+    int* overflow;
+    const int* cols;        // not null: the launch codes columns cols[0 .. *n_cols - 1] (the overflow list)
+    const int* n_cols;
 };
 
 // The inverse of the active Gram matrix, indexed by slot.  PACKED: lower triangle, row after row (LDS);
-// else a full square with leading dimension 64 Q (global memory: rows are read coalesced).
+// else a full square with leading dimension ld (global memory: rows are read coalesced).
 template <bool PACKED>
 struct Inv {
     double* p;
@@ -167,32 +206,36 @@ struct Inv {
     __device__ __forceinline__ bool mine(int i, int j) const { return PACKED ? j <= i : true; }
 };
 
-template <int Q, bool P_LDS>
+// Q: atoms per lane (r <= 64 Q); SQ: slots per lane (n_cap <= 64 SQ)
+template <int Q, int SQ, bool P_LDS>
 __global__ __launch_bounds__(256) void lars_pos_kernel(const LarsArgs a) {
     extern __shared__ __attribute__((aligned(16))) double lds_raw[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpg = blockDim.x >> 6;
-    const int r = a.r;
-    double* lsv = lds_raw + (size_t)wave * a.wave_doubles;      // direction by slot (r doubles)
+    const int r = a.r, n_cap = a.n_cap;
+    double* lsv = lds_raw + (size_t)wave * a.wave_doubles;      // direction by slot (n_cap doubles)
     Inv<P_LDS> P;
     if (P_LDS) {
-        P.p = lsv + ((r + 1) & ~1);
+        P.p = lsv + ((n_cap + 1) & ~1);
         P.ld = 0;
     } else {
         P.p = a.Pws + (size_t)(blockIdx.x * wpg + wave) * a.p_stride;
-        P.ld = 64 * Q;
+        P.ld = 64 * SQ;
     }
     const double* __restrict__ G = a.G;
     const double tiny32 = (double)FLT_MIN, eq_tol = (double)FLT_EPSILON;
     const double alpha_min = a.alpha / a.n_samples;
+    const int n_cols = a.cols ? *a.n_cols : a.b;
+    int peak_slots = 0;
 
-    for (int col = blockIdx.x * wpg + wave; col < a.b; col += gridDim.x * wpg) {
+    for (int ci = blockIdx.x * wpg + wave; ci < n_cols; ci += gridDim.x * wpg) {
+        const int col = a.cols ? a.cols[ci] : ci;
         // atom space (atom j = lane + 64 q)
         double xy[Q], cov[Q], coef[Q], prev[Q];
         int slot[Q];
         // slot space (slot k = lane + 64 q)
-        int act[Q];
-        double w[Q];
-        unsigned long long used[Q];
+        int act[SQ];
+        double w[SQ];
+        unsigned long long used[SQ];
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
             const int j = lane + 64 * q;
@@ -200,6 +243,9 @@ __global__ __launch_bounds__(256) void lars_pos_kernel(const LarsArgs a) {
             cov[q] = xy[q];
             coef[q] = prev[q] = 0.0;
             slot[q] = -1;
+        }
+#pragma unroll
+        for (int q = 0; q < SQ; ++q) {
             act[q] = 0;
             w[q] = 0.0;
             used[q] = 0ull;
@@ -208,23 +254,23 @@ __global__ __launch_bounds__(256) void lars_pos_kernel(const LarsArgs a) {
         // every trip of the loop below is an event or a skipped degenerate atom (at most r of those between
         // two events in the library; the bound makes sure that every wave leaves the loop whatever the data)
         int trips_left = a.max_iter + 2 * r + 8;
-        bool drop = false;
+        bool drop = false, overflow = false;
         double alpha = 0.0, prev_alpha = 0.0;
 
         auto slot_used = [&](int q) -> bool { return (used[q] >> lane) & 1ull; };
         // w = column sums of the inverse over the used slots
         auto column_sums = [&]() {
 #pragma unroll
-            for (int q = 0; q < Q; ++q) w[q] = 0.0;
+            for (int q = 0; q < SQ; ++q) w[q] = 0.0;
 #pragma unroll
-            for (int qi = 0; qi < Q; ++qi) {
+            for (int qi = 0; qi < SQ; ++qi) {
                 unsigned long long m = used[qi];
                 while (m) {
                     const int ii = __builtin_ctzll(m);
                     m &= m - 1;
                     const int i = 64 * qi + ii;
 #pragma unroll
-                    for (int q = 0; q < Q; ++q)
+                    for (int q = 0; q < SQ; ++q)
                         if (slot_used(q)) w[q] += P.at(i, lane + 64 * q);
                 }
             }
@@ -266,15 +312,16 @@ __global__ __launch_bounds__(256) void lars_pos_kernel(const LarsArgs a) {
             }
             if (!drop) {                                             // :671-741: atom c_idx enters
                 const int v = c_idx;
-                double g[Q], u[Q];
+                double g[SQ], u[SQ];
 #pragma unroll
-                for (int q = 0; q < Q; ++q) {
+                for (int q = 0; q < SQ; ++q) {
                     g[q] = slot_used(q) ? G[(size_t)v * r + act[q]] : 0.0;
                     u[q] = 0.0;
                 }
+                const double gvv = G[(size_t)v * r + v];
                 // u = inverse . g
 #pragma unroll
-                for (int qi = 0; qi < Q; ++qi) {
+                for (int qi = 0; qi < SQ; ++qi) {
                     unsigned long long m = used[qi];
                     while (m) {
                         const int ii = __builtin_ctzll(m);
@@ -282,15 +329,15 @@ __global__ __launch_bounds__(256) void lars_pos_kernel(const LarsArgs a) {
                         const int i = 64 * qi + ii;
                         const double gi = lane_value(g[qi], ii);
 #pragma unroll
-                        for (int q = 0; q < Q; ++q)
+                        for (int q = 0; q < SQ; ++q)
                             if (slot_used(q)) u[q] += P.at(i, lane + 64 * q) * gi;
                     }
                 }
                 double gu = 0.0;
 #pragma unroll
-                for (int q = 0; q < Q; ++q) gu += g[q] * u[q];
-                gu = wave_sum(gu);
-                const double s = G[(size_t)v * r + v] - gu;          // Schur complement = pivot^2 (:715-717)
+                for (int q = 0; q < SQ; ++q) gu += g[q] * u[q];
+                gu = uni(wave_sum(gu));
+                const double s = gvv - gu;                           // Schur complement = pivot^2 (:715-717)
                 const double diag = fmax(sqrt(fabs(s)), DBL_EPSILON);
                 if (diag < 1e-7) {                                   // :719-738
 #pragma unroll
@@ -299,13 +346,18 @@ __global__ __launch_bounds__(256) void lars_pos_kernel(const LarsArgs a) {
                     continue;
                 }
                 const double sinv = 1.0 / (diag * diag);
-                int knew = 0;
+                int knew = 64 * SQ;
 #pragma unroll
-                for (int q = Q - 1; q >= 0; --q)
+                for (int q = SQ - 1; q >= 0; --q)
                     if (~used[q]) knew = 64 * q + __builtin_ctzll(~used[q]);
+                if (knew >= n_cap) {                                 // no room: the second launch codes this column
+                    overflow = true;
+                    break;
+                }
+                peak_slots = max(peak_slots, knew + 1);
                 // inverse += u u^T / s over the used slots; the new slot's row and column
 #pragma unroll
-                for (int qi = 0; qi < Q; ++qi) {
+                for (int qi = 0; qi < SQ; ++qi) {
                     unsigned long long m = used[qi];
                     while (m) {
                         const int ii = __builtin_ctzll(m);
@@ -313,14 +365,14 @@ __global__ __launch_bounds__(256) void lars_pos_kernel(const LarsArgs a) {
                         const int i = 64 * qi + ii;
                         const double ui = lane_value(u[qi], ii);
 #pragma unroll
-                        for (int q = 0; q < Q; ++q) {
+                        for (int q = 0; q < SQ; ++q) {
                             const int k = lane + 64 * q;
                             if (slot_used(q) && P.mine(i, k)) P.at(i, k) += (ui * u[q]) * sinv;
                         }
                     }
                 }
 #pragma unroll
-                for (int q = 0; q < Q; ++q) {
+                for (int q = 0; q < SQ; ++q) {
                     const int k = lane + 64 * q;
                     if (slot_used(q)) {
                         P.at(knew, k) = -u[q] * sinv;
@@ -330,10 +382,12 @@ __global__ __launch_bounds__(256) void lars_pos_kernel(const LarsArgs a) {
                         P.at(knew, knew) = sinv;
                         act[q] = v;
                     }
-                    if (lane + 64 * q == v) slot[q] = knew;
                 }
 #pragma unroll
                 for (int q = 0; q < Q; ++q)
+                    if (lane + 64 * q == v) slot[q] = knew;
+#pragma unroll
+                for (int q = 0; q < SQ; ++q)
                     if ((knew >> 6) == q) used[q] |= 1ull << (knew & 63);
                 ++n_active;
                 pass_fence();
@@ -346,13 +400,13 @@ __global__ __launch_bounds__(256) void lars_pos_kernel(const LarsArgs a) {
             // equiangular direction (:764-788): least_squares = inverse . 1, scaled by AA
             double sw = 0.0;
 #pragma unroll
-            for (int q = 0; q < Q; ++q) sw += slot_used(q) ? w[q] : 0.0;
-            sw = wave_sum(sw);
+            for (int q = 0; q < SQ; ++q) sw += slot_used(q) ? w[q] : 0.0;
+            sw = uni(wave_sum(sw));
             double AA = 1.0 / sqrt(sw);
             if (!(fabs(AA) <= DBL_MAX)) AA = 1.0 / sqrt(fmax(sw, DBL_EPSILON));
-            double ls[Q];
+            double ls[SQ];
 #pragma unroll
-            for (int q = 0; q < Q; ++q) {
+            for (int q = 0; q < SQ; ++q) {
                 ls[q] = slot_used(q) ? w[q] * AA : 0.0;
                 if (slot_used(q)) lsv[lane + 64 * q] = ls[q];
             }
@@ -362,7 +416,7 @@ __global__ __launch_bounds__(256) void lars_pos_kernel(const LarsArgs a) {
 #pragma unroll
             for (int q = 0; q < Q; ++q) corr[q] = 0.0;
 #pragma unroll
-            for (int qi = 0; qi < Q; ++qi) {
+            for (int qi = 0; qi < SQ; ++qi) {
                 unsigned long long m = used[qi];
                 while (m) {
                     const int ii = __builtin_ctzll(m);
@@ -420,30 +474,27 @@ __global__ __launch_bounds__(256) void lars_pos_kernel(const LarsArgs a) {
 #pragma unroll
                     for (int q = Q - 1; q >= 0; --q)
                         if (slot[q] >= 0 && z[q] == z_pos) cand = lane + 64 * q;
-#pragma unroll
-                    for (int off = 32; off > 0; off >>= 1) cand = min(cand, __shfl_xor(cand, off));
-                    const int v = uni(cand);
+                    const int v = uni(wave_min(cand));
                     if (v == INT_MAX) break;
-                    int kq = 0;
+                    int k = 0;
 #pragma unroll
                     for (int q = 0; q < Q; ++q)
-                        if ((v >> 6) == q) kq = __builtin_amdgcn_readlane(slot[q], v & 63);
-                    const int k = kq;
-                    double p[Q];
+                        if ((v >> 6) == q) k = __builtin_amdgcn_readlane(slot[q], v & 63);
+                    double p[SQ];
 #pragma unroll
-                    for (int q = 0; q < Q; ++q) p[q] = slot_used(q) ? P.at(k, lane + 64 * q) : 0.0;
+                    for (int q = 0; q < SQ; ++q) p[q] = slot_used(q) ? P.at(k, lane + 64 * q) : 0.0;
                     double pkk = 0.0;
 #pragma unroll
-                    for (int q = 0; q < Q; ++q)
+                    for (int q = 0; q < SQ; ++q)
                         if ((k >> 6) == q) pkk = lane_value(p[q], k & 63);
                     const double pinv = 1.0 / pkk;
 #pragma unroll
-                    for (int q = 0; q < Q; ++q)
+                    for (int q = 0; q < SQ; ++q)
                         if ((k >> 6) == q) used[q] &= ~(1ull << (k & 63));
                     pass_fence();
                     // inverse of the remaining atoms: inverse -= p p^T / p_kk
 #pragma unroll
-                    for (int qi = 0; qi < Q; ++qi) {
+                    for (int qi = 0; qi < SQ; ++qi) {
                         unsigned long long m = used[qi];
                         while (m) {
                             const int ii = __builtin_ctzll(m);
@@ -451,7 +502,7 @@ __global__ __launch_bounds__(256) void lars_pos_kernel(const LarsArgs a) {
                             const int i = 64 * qi + ii;
                             const double pi = lane_value(p[qi], ii);
 #pragma unroll
-                            for (int q = 0; q < Q; ++q) {
+                            for (int q = 0; q < SQ; ++q) {
                                 const int kk = lane + 64 * q;
                                 if (slot_used(q) && P.mine(i, kk)) P.at(i, kk) -= (pi * p[q]) * pinv;
                             }
@@ -464,7 +515,7 @@ __global__ __launch_bounds__(256) void lars_pos_kernel(const LarsArgs a) {
                         const int j = lane + 64 * q;
                         if (j < r) dot += G[(size_t)v * r + j] * coef[q];
                     }
-                    dot = wave_sum(dot);
+                    dot = uni(wave_sum(dot));
 #pragma unroll
                     for (int q = 0; q < Q; ++q)
                         if (lane + 64 * q == v) {
@@ -479,57 +530,125 @@ __global__ __launch_bounds__(256) void lars_pos_kernel(const LarsArgs a) {
                 column_sums();
             }
         }
+        if (overflow) {
+            if (lane == 0) {
+                const int at = __hip_atomic_fetch_add(a.meta, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                a.overflow[at] = col;
+            }
+        } else {
 #pragma unroll
-        for (int q = 0; q < Q; ++q) {
-            const int j = lane + 64 * q;
-            if (j < r) a.H[(size_t)j * a.ldh + col] = (float)coef[q];
-        }
-        if (a.info && lane == 0) {
-            int* rec = a.info + 4 * (size_t)col;
-            rec[0] = n_iter;
-            rec[1] = end;
-            rec[2] = n_active;
-            rec[3] = n_drops;
+            for (int q = 0; q < Q; ++q) {
+                const int j = lane + 64 * q;
+                if (j < r) a.H[(size_t)j * a.ldh + col] = (float)coef[q];
+            }
+            if (a.info && lane == 0) {
+                int* rec = a.info + 4 * (size_t)col;
+                rec[0] = n_iter;
+                rec[1] = end;
+                rec[2] = n_active;
+                rec[3] = n_drops;
+            }
         }
         pass_fence();
     }
+    if (lane == 0 && peak_slots > 0)
+        __hip_atomic_fetch_max(a.meta + 1, peak_slots, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-LdsLimit g_lds_lars[8];
+// behind the launches of a call: the most slots a column used goes to host memory the device can write (the
+// next call sizes its first launch by it), and the two words are cleared for that call
+__global__ void lars_publish_kernel(int* meta, int* host_words, int r) {
+    host_words[0] = meta[1];
+    host_words[1] = r;
+    host_words[2] += meta[0];          // columns coded by a second launch since the context was created
+    meta[0] = 0;
+    meta[1] = 0;
+}
+
+constexpr int LARS_HOST_WORDS = ONMF_LARS_HOST_WORDS;      // first of the three words above in onmf_ctx::host_events
+
+template <int Q, int SQ, bool P_LDS>
+int launch_lars_form(onmf_ctx* c, LarsArgs a, int n_cap, bool second, hipStream_t s) {
+    static LdsLimit lds_limit;
+    const int wpg = 4;
+    a.n_cap = n_cap;
+    const size_t ls_doubles = (size_t)((n_cap + 1) & ~1);
+    auto kern = lars_pos_kernel<Q, SQ, P_LDS>;
+    int grid;
+    size_t lds;
+    if (P_LDS) {
+        const size_t packed = ((size_t)n_cap * (n_cap + 1) / 2 + 1) & ~(size_t)1;
+        a.wave_doubles = (int)(ls_doubles + packed);
+        int waves = wpg;
+        lds = (size_t)a.wave_doubles * sizeof(double) * waves;
+        while (lds > 160 * 1024 && waves > 1) lds = (size_t)a.wave_doubles * sizeof(double) * --waves;
+        if (lds > 160 * 1024) return onmf_fail(c, ONMF_ERR_ARG, "LARS coder: %d slots do not fit in LDS", n_cap);
+        if (lds > 48 * 1024) ONMF_TRY(onmf_raise_lds_limit(c, lds_limit, (const void*)kern, lds));
+        grid = (a.b + waves - 1) / waves;
+        if (second && grid > 1024) grid = 1024;       // few columns overflow; the kernel strides over its list
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * waves), lds, s, a);
+    } else {
+        // the inverse in global memory: a bounded number of waves, each with its own square
+        const size_t stride = (size_t)(64 * SQ) * (64 * SQ);
+        const int waves_total = a.b < 2048 ? a.b : 2048;
+        grid = (waves_total + wpg - 1) / wpg;
+        ONMF_TRY(onmf_reserve(c, c->lars_ws, (size_t)grid * wpg * stride * sizeof(double), "LARS workspace"));
+        a.Pws = (double*)c->lars_ws.p;
+        a.p_stride = stride;
+        a.wave_doubles = (int)ls_doubles;
+        lds = ls_doubles * sizeof(double) * wpg;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * wpg), lds, s, a);
+    }
+    if (hipGetLastError() != hipSuccess) return onmf_fail(c, ONMF_ERR_HIP, "LARS coder: launch failed");
+    return ONMF_OK;
+}
+
+// packed inverse of n slots + the direction vector, per wave
+size_t lars_lds_bytes(int n) { return ((((size_t)n + 1) & ~(size_t)1) + ((((size_t)n * (n + 1) / 2) + 1) & ~(size_t)1)) * 8; }
 
 template <int Q>
 int launch_lars_q(onmf_ctx* c, const LarsArgs& a0, hipStream_t s) {
     LarsArgs a = a0;
     const int r = a.r;
-    const size_t packed = (size_t)r * (r + 1) / 2;
-    const size_t ls_doubles = (size_t)((r + 1) & ~1);
-    const size_t lds_budget = 160 * 1024;
-    const size_t per_wave_lds = (ls_doubles + ((packed + 1) & ~(size_t)1)) * sizeof(double);
-    if (per_wave_lds <= lds_budget) {
-        int wpg = (int)(lds_budget / per_wave_lds);
-        if (wpg > 4) wpg = 4;
-        a.wave_doubles = (int)(per_wave_lds / sizeof(double));
-        a.Pws = nullptr;
-        a.p_stride = 0;
-        const size_t lds = per_wave_lds * wpg;
-        auto kern = lars_pos_kernel<Q, true>;
-        if (lds > 48 * 1024) ONMF_TRY(onmf_raise_lds_limit(c, g_lds_lars[Q - 1], (const void*)kern, lds));
-        const int grid = (a.b + wpg - 1) / wpg;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * wpg), lds, s, a);
-    } else {
-        // the inverse in global memory: a bounded number of waves, each with its own square
-        const int wpg = 4;
-        const size_t stride = (size_t)(64 * Q) * (64 * Q);
-        int waves = a.b < 1024 ? a.b : 1024;
-        const int grid = (waves + wpg - 1) / wpg;
-        ONMF_TRY(onmf_reserve(c, c->lars_ws, (size_t)grid * wpg * stride * sizeof(double), "LARS workspace"));
-        a.Pws = (double*)c->lars_ws.p;
-        a.p_stride = stride;
-        a.wave_doubles = (int)ls_doubles;
-        const size_t lds = ls_doubles * sizeof(double) * wpg;
-        hipLaunchKernelGGL((lars_pos_kernel<Q, false>), dim3(grid), dim3(64 * wpg), lds, s, a);
+    // state of the call: two device words, and room for the indices of the columns that overflow
+    const bool fresh = c->lars_meta.p == nullptr;
+    ONMF_TRY(onmf_reserve(c, c->lars_meta, 16 * sizeof(int), "LARS state"));
+    if (fresh) HIP_TRY(c, hipMemsetAsync(c->lars_meta.p, 0, 16 * sizeof(int), s));
+    ONMF_TRY(onmf_reserve(c, c->lars_overflow, (size_t)a.b * sizeof(int), "LARS overflow list"));
+    a.meta = (int*)c->lars_meta.p;
+    a.overflow = (int*)c->lars_overflow.p;
+    // the most slots a column of the previous call used (same r): the first launch gets a quarter more,
+    // which lets several waves per SIMD be resident; columns that need more go to the second launch
+    volatile int* hw = c->host_events + LARS_HOST_WORDS;
+    const int hint = (hw[1] == r && c->lars_hint_ok) ? hw[0] : -1;
+    int n_cap = r;
+    if (c->lars_slots > 0) {
+        n_cap = c->lars_slots < r ? c->lars_slots : r;
+        if (n_cap > 64 && n_cap < r) n_cap = 64;
+    } else if (hint >= 0) {
+        const int want = hint + hint / 4 + 4;
+        for (int cand : {16, 32, 48, 64})
+            if (want <= cand && cand < r) {
+                n_cap = cand;
+                break;
+            }
     }
+    const bool full_fits = lars_lds_bytes(r) <= 160 * 1024;
+    if (n_cap < r) {
+        ONMF_TRY((launch_lars_form<Q, 1, true>(c, a, n_cap, false, s)));
+        LarsArgs a2 = a;
+        a2.cols = a.overflow;
+        a2.n_cols = a.meta;
+        if (full_fits) ONMF_TRY((launch_lars_form<Q, Q, true>(c, a2, r, true, s)));
+        else ONMF_TRY((launch_lars_form<Q, Q, false>(c, a2, r, true, s)));
+    } else if (full_fits) {
+        ONMF_TRY((launch_lars_form<Q, Q, true>(c, a, r, false, s)));
+    } else {
+        ONMF_TRY((launch_lars_form<Q, Q, false>(c, a, r, false, s)));
+    }
+    hipLaunchKernelGGL(lars_publish_kernel, dim3(1), dim3(1), 0, s, a.meta, c->host_events_dev + LARS_HOST_WORDS, r);
     if (hipGetLastError() != hipSuccess) return onmf_fail(c, ONMF_ERR_HIP, "LARS coder: launch failed");
+    c->lars_hint_ok = true;
     return ONMF_OK;
 }
 

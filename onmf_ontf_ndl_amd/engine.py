@@ -97,7 +97,7 @@ class Engine:
         out = {}
         for name, key in (("sweep_timeouts", _lib.CNT_SWEEP_TIMEOUTS), ("dict_timeouts", _lib.CNT_DICT_TIMEOUTS),
                           ("fallback_solves", _lib.CNT_FALLBACK_SOLVES),
-                          ("device_resolves", _lib.CNT_DEVICE_RESOLVES)):
+                          ("device_resolves", _lib.CNT_DEVICE_RESOLVES), ("lars_recoded", _lib.CNT_LARS_RECODED), ("lars_slots_used", _lib.CNT_LARS_SLOTS_USED)):
             v = C.c_longlong(0)
             _lib.check(self.lib.onmf_get_counter(self.ctx, key, C.byref(v)), self.ctx, "onmf_get_counter")
             out[name] = int(v.value)

@@ -187,3 +187,50 @@ def test_lars_coder_every_register_and_storage_form(orc, r, d, b, alpha):
     assert np.all(info[:, 1] == 1)
     if r == 5:
         assert np.all(H[3] == 0) and info[3, 0] == 0
+
+
+def test_lars_coder_second_launch_for_columns_that_outgrow_their_slots(orc):
+    """A call sizes its first launch by the active-set sizes of the call before; columns that need more slots
+    are coded again by a second launch with room for every atom.  Forced here (16 slots for columns that hold
+    up to ~40 atoms), and through the history rule: a sparse call (large penalty) followed by a dense one."""
+    from onmf_ontf_ndl_amd import _lib
+    from onmf_ontf_ndl_amd.engine import get_engine
+    eng = get_engine()
+    rs = np.random.RandomState(77)
+    d, r, b = 120, 90, 150
+    W = rs.rand(d, r).astype(np.float32)
+    W /= np.linalg.norm(W, axis=0).astype(np.float32)
+    X = rs.rand(d, b).astype(np.float32)
+    want = orc.lars_pos_code(X.astype(np.float64), W.astype(np.float64), 0.3)
+    active = (want > 1e-12).sum(axis=1)
+    assert active.max() > 20 and active.min() < 64
+    Xd, Wd = eng.dev(X), eng.dev(W)
+    host = lambda t: t.cpu().numpy().astype(np.float64).T
+    import torch
+    before = eng.counters()["lars_recoded"]
+    try:
+        eng.set_option(_lib.OPT_LARS_SLOTS, 16)
+        H16, info = eng.sparse_code_lars(Xd, Wd, alpha=0.3, want_info=True)
+        torch.cuda.synchronize()
+        recoded = eng.counters()["lars_recoded"] - before
+        eng.set_option(_lib.OPT_LARS_SLOTS, 64)
+        H64 = eng.sparse_code_lars(Xd, Wd, alpha=0.3)
+    finally:
+        eng.set_option(_lib.OPT_LARS_SLOTS, 0)
+    print("forced: %d of %d columns recoded; rel err %.2e" % (recoded, b, relerr(host(H16), want)))
+    assert 0 < recoded <= b
+    assert relerr(host(H16), want) < 1e-5 and torch.equal(H16, H64)
+    assert np.all(info.cpu().numpy()[:, 1] == 1)
+    # history rule: after a sparse call the first launch is small, and the dense call still comes out right
+    Hs = eng.sparse_code_lars(Xd, Wd, alpha=5.0)
+    torch.cuda.synchronize()
+    print("slots used by the sparse call:", eng.counters()["lars_slots_used"])
+    assert eng.counters()["lars_slots_used"] <= 9          # -> 16 slots in the next call's first launch
+    before = eng.counters()["lars_recoded"]
+    Hd = eng.sparse_code_lars(Xd, Wd, alpha=0.3)
+    torch.cuda.synchronize()
+    print("after a sparse call: %d columns recoded, slots used %d" % (eng.counters()["lars_recoded"] - before,
+                                                                     eng.counters()["lars_slots_used"]))
+    assert eng.counters()["lars_recoded"] > before
+    assert torch.equal(Hd, H16)
+    assert relerr(host(Hs), orc.lars_pos_code(X.astype(np.float64), W.astype(np.float64), 5.0)) < 1e-5
