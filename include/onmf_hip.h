@@ -118,9 +118,12 @@ int onmf_update_dict(onmf_ctx* ctx, int d, int r, const float* W_in, const float
  * library - 4.25 MB per GPU the library runs on, held until the process ends - instead of buffers the
  * context allocates on demand.  Limits: d <= 1024 and r <= 256 (larger shapes return ONMF_ERR_ARG:
  * use onmf_update_dict).  Calls neither hipMalloc nor hipFree nor any other allocating routine; asynchronous on `stream`,
- * returns no host scalars.  Every call on a GPU uses that GPU's one array: calls that overlap on one
- * GPU (two streams, two contexts, two threads) race.  Nothing carries over between calls - each call
- * rewrites every part of the array that it reads.
+ * returns no host scalars.  Every call on a GPU uses that GPU's one array.  Calls from this process are
+ * ordered behind each other on the GPU whatever stream, context or thread they come from (an event per
+ * device, created by onmf_create, recorded behind each call and waited for by the next) - except calls
+ * on a stream that is being captured, which are left unordered: calls that overlap on one GPU under
+ * capture, or from two processes, race.  Nothing carries over between calls - each call rewrites every
+ * part of the array that it reads.
  */
 int onmf_update_dict_static(onmf_ctx* ctx, int d, int r, const float* W_in, const float* A, const float* B,
                             float* W_out, void* stream);

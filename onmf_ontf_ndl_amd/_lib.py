@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libonmf_hip.so")
+# ONMF_HIP_LIB: another build of the same library (diagnostic builds, A/B comparisons) without touching this one
+LIB_PATH = os.environ.get("ONMF_HIP_LIB") or os.path.join(_HERE, "libonmf_hip.so")
 
 OK = 0
 CODER_DAMPED = 0

@@ -8,6 +8,7 @@
 #include "common.h"
 
 #include <functional>
+#include <mutex>
 
 // ---------------------------------------------------------------------------------------------
 // context helpers
@@ -83,6 +84,13 @@ constexpr size_t STATIC_SCRATCH_FLOATS =
     4 * (size_t)STATIC_DICT_MAX_D * STATIC_DICT_MAX_R + (size_t)STATIC_DICT_MAX_R * STATIC_DICT_MAX_R;   // 4.25 MB
 static __device__ __align__(256) float scratch[STATIC_SCRATCH_FLOATS];
 static float* g_scratch_ptr[LdsLimit::MAX_DEV];     // per device, filled by onmf_create
+// Calls that use the one array of a GPU are ordered behind each other, whatever stream or context they come
+// from: an event per device (created by onmf_create, so the entry point itself creates nothing), recorded
+// behind every call and waited for by the next.  A capturing stream is left alone (an event recorded outside
+// a capture has no place in it): under capture the caller keeps such calls apart.
+static hipEvent_t g_scratch_event[LdsLimit::MAX_DEV];
+static bool g_scratch_event_recorded[LdsLimit::MAX_DEV];
+static std::mutex g_scratch_mutex;
 
 // with `device` current
 static int static_scratch_for_device(int device, float** out) {
@@ -97,6 +105,14 @@ static int static_scratch_for_device(int device, float** out) {
             return onmf_fail(nullptr, ONMF_ERR_HIP, "hipGetSymbolAddress(scratch) on device %d: %s", device,
                              hipGetErrorString(e));
         g_scratch_ptr[device] = ptr;
+    }
+    {
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        if (!g_scratch_event[device] &&
+            hipEventCreateWithFlags(&g_scratch_event[device], EV_ORDER_ONLY) != hipSuccess) {
+            g_scratch_event[device] = nullptr;
+            return onmf_fail(nullptr, ONMF_ERR_HIP, "creating the static scratch's event on device %d failed", device);
+        }
     }
     *out = g_scratch_ptr[device];
     return ONMF_OK;
@@ -841,9 +857,20 @@ int onmf_update_dict_static(onmf_ctx* c, int d, int r, const float* W_in, const 
                          "onmf_update_dict", d, r, STATIC_DICT_MAX_D, STATIC_DICT_MAX_R);
     if (!c->static_scratch) return onmf_fail(c, ONMF_ERR_HIP, "update_dict_static: no static scratch on this device");
     ONMF_ENTER(c);
+    hipStream_t s = (hipStream_t)stream;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s, &capture);
+    const bool ordered = capture == hipStreamCaptureStatusNone && g_scratch_event[c->device];
+    if (ordered && g_scratch_event_recorded[c->device]) HIP_TRY(c, hipStreamWaitEvent(s, g_scratch_event[c->device], 0));
     // one workgroup does the whole pass (d <= 1024): no waits between workgroups, no flag to read back,
     // nothing to clear - the head kernel rewrites every part of the workspace the pass reads
-    return launch_dict_pass(c, d, r, W_in, A, B, W_out, (hipStream_t)stream, 0, c->static_scratch);
+    const int rc = launch_dict_pass(c, d, r, W_in, A, B, W_out, s, 0, c->static_scratch);
+    if (ordered) {
+        HIP_TRY(c, hipEventRecord(g_scratch_event[c->device], s));
+        g_scratch_event_recorded[c->device] = true;
+    }
+    return rc;
 }
 
 }  // extern "C"

@@ -305,6 +305,16 @@ __device__ __forceinline__ int screen_verdict(float lb2, double dsum, double hsu
     return verdict;
 }
 
+// Everything a workgroup reads of what ANOTHER workgroup of the same launch wrote goes through agent-scope
+// atomics (relaxed): the accumulator sets, the completion counts, the flag, and the bounds below.  The
+// kernels rely on no ordering beyond "an atomic whose value has come back has been performed": a workgroup
+// waits for the values its own atomic adds return before it bumps the count, so whoever sees the count
+// complete finds all sums performed.  Plain loads are used only for data that no workgroup of the launch
+// writes (the probe blocks, the positive vector).
+__device__ __forceinline__ float screen_load_bound(const float* base, int k) {
+    return __hip_atomic_load(base + ScreenLayout::UBH + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // The same for sweep j, from its accumulator set; called by all 64 lanes of one wave.  The set is
 // read with agent-scope atomic loads: within a launch the sums come from workgroups on other XCDs,
 // whose stores a plain load could miss in this XCD's L2.  `ub` carries the bound of
@@ -361,7 +371,7 @@ __device__ __forceinline__ int screen_eval_wave(float* base, int j, float& ub, f
         // a bound for the next sweep that was put there before the launch (Collatz-Wielandt, or the
         // host's exact value) stands if it is the tighter one; every workgroup reads the same value
         // or the minimum already taken with it, so all arrive at the same number
-        const float seeded = seeded_in >= 0.f ? seeded_in : base[ScreenLayout::UBH + j + 1];
+        const float seeded = seeded_in >= 0.f ? seeded_in : screen_load_bound(base, j + 1);
         if (seeded > 0.f && seeded < ubn) ubn = seeded;
         // (1 + 1e-4 on the square: fp32 rounding of the sums behind y)
         if (cw_ratio > 0.f && cw_ratio < 3.0e38f) {
@@ -374,7 +384,7 @@ __device__ __forceinline__ int screen_eval_wave(float* base, int j, float& ub, f
             rec[1] = upper;
             rec[2] = (float)(verdict + 1);                    // 0 = no verdict yet
             rec[3] = ubh;
-            base[ScreenLayout::UBH + j + 1] = ubn;
+            __hip_atomic_store(base + ScreenLayout::UBH + j + 1, ubn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (verdict != 0)
                 __hip_atomic_store(reinterpret_cast<int*>(base) + ScreenLayout::FLAG, verdict, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);

@@ -266,7 +266,7 @@ __global__ __launch_bounds__(64 * WPG) void sweep_tile_kernel(
                 if (j >= v_first) {
                     const int* cnt = reinterpret_cast<const int*>(sc.base) + ScreenLayout::CNT + j;
                     // (requested together with the first look at the count; 0 = none, as negative)
-                    const float seeded = tested_ahead ? 0.f : fmaxf(sc.base[ScreenLayout::UBH + j + 1], 0.f);
+                    const float seeded = tested_ahead ? 0.f : fmaxf(screen_load_bound(sc.base, j + 1), 0.f);
                     const long long t0 = wall_clock64();
                     while (!tested_ahead) {
                         // (the sums are read only after the count has been seen complete: they were
@@ -623,7 +623,7 @@ __global__ __launch_bounds__(64 * WPG) void sweep_tile_kernel(
                 const int seen = __builtin_amdgcn_readfirstlane(
                     __hip_atomic_load(reinterpret_cast<const int*>(sc.base) + ScreenLayout::CNT + k - 1, __ATOMIC_RELAXED,
                                       __HIP_MEMORY_SCOPE_AGENT));
-                const float seeded = fmaxf(sc.base[ScreenLayout::UBH + k], 0.f);
+                const float seeded = fmaxf(screen_load_bound(sc.base, k), 0.f);
                 SWEEP_MARK(8);
                 if (seen >= (int)gridDim.x && sc.spin_limit != SPIN_FORCE_TIMEOUT) {
                     verdict_ahead = screen_eval_wave(sc.base, k - 1, ub, sc.tol, sc.rank_cap, blockIdx.x == 0, seeded,

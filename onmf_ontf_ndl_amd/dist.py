@@ -183,6 +183,51 @@ def sharded_step(eng, X_local, A, B, W, w, *, alpha=0.0, H0=None, seed=None, sub
     return H, A1, B1, W1, sweeps
 
 
+class _CommStream:
+    """Where ``ShardedStepper`` runs a step's exchange: a HIP stream of its own (default priority), ordered
+    behind what the main stream holds at that moment.  ``after_main(fn)`` returns an event that fires when
+    ``fn``'s work is done."""
+
+    def __init__(self, device):
+        import torch
+        self.device = device
+        self.comm = torch.cuda.Stream(device=device)
+
+    def after_main(self, fn):
+        import torch
+        main = torch.cuda.current_stream(self.device)
+        done = torch.cuda.Event()
+        done.record(main)
+        with torch.cuda.stream(self.comm):
+            self.comm.wait_event(done)
+            fn()
+            ready = torch.cuda.Event()
+            ready.record(self.comm)
+        return ready
+
+    def sync_main(self):
+        import torch
+        torch.cuda.current_stream(self.device).synchronize()
+
+
+class _Inline:
+    """The same interface with nothing to overlap: the exchange runs at once (host tensors; a ``gloo``
+    group, whose collective is staged through the host anyway)."""
+
+    def __init__(self, device=None):
+        self.device = device
+
+    def after_main(self, fn):
+        self.sync_main()
+        fn()
+        return None
+
+    def sync_main(self):
+        if self.device is not None and getattr(self.device, "type", "cpu") == "cuda":
+            import torch
+            torch.cuda.current_stream(self.device).synchronize()
+
+
 class ShardedStepper:
     """The column-split step with the library's own schedule and the exchange off the critical path.
 
@@ -193,10 +238,12 @@ class ShardedStepper:
     The next step's code solve starts at once (it needs W_{t+1} only); its dictionary pass and its own
     sums wait for the event inside the library.  Buffers alternate between two sets, so nothing a
     pending exchange reads is overwritten.
+
+    ``sched`` (optional) is where the exchange runs (``after_main(fn) -> event``, ``sync_main()``): by
+    default a stream of its own on the engine's GPU, or inline when the collective is host-staged.
     """
 
-    def __init__(self, eng, W, A, B, group=None):
-        import torch
+    def __init__(self, eng, W, A, B, group=None, sched=None):
         self.eng, self.group = eng, group
         d, r = W.shape
         self.d, self.r = d, r
@@ -206,7 +253,12 @@ class ShardedStepper:
         self.P = [eng.zeros(eng.partial_floats(d, r)) for _ in range(2)]
         self.cur = 0
         self.ready = None                       # event: (A, B)[cur] are final and P[1 - cur] is free
-        self.comm = torch.cuda.Stream(device=eng.device)      # default priority
+        if sched is None:
+            import torch.distributed as td
+            staged = _active(group) and td.get_world_size(group) > 1 and td.get_backend(group) == "gloo"
+            on_gpu = getattr(eng.device, "type", "cpu") == "cuda"
+            sched = _CommStream(eng.device) if (on_gpu and not staged) else _Inline(eng.device)
+        self.sched = sched
         self.sweeps = None
 
     def state(self):
@@ -217,30 +269,19 @@ class ShardedStepper:
         return self.W[c], self.A[c], self.B[c]
 
     def step(self, X_local, w, *, alpha=0.0, H0=None, seed=None, sub_iter=10, stopping_diff=0.0, want_code=True):
-        import torch
-        import torch.distributed as td
         eng, c, n = self.eng, self.cur, 1 - self.cur
         P = self.P[c]
         H, _, self.sweeps = eng.step_partial(X_local, self.A[c], self.B[c], self.W[c], P, W_out=self.W[n], alpha=alpha,
                                              H0=H0, seed=seed, sub_iter=sub_iter, stopping_diff=stopping_diff,
                                              want_code=want_code, state_ready_event=self.ready)
-        main = torch.cuda.current_stream(eng.device)
-        done = torch.cuda.Event()
-        done.record(main)
-        multi = _active(self.group) and td.get_world_size(self.group) > 1
-        if multi and td.get_backend(self.group) == "gloo":
-            main.synchronize()                   # host-staged collective: nothing to overlap with
-            all_reduce_sum(P, self.group)
-            eng.step_apply(P, w, self.A[c], self.B[c], self.A[n], self.B[n])
-            self.ready = None
-        else:
-            with torch.cuda.stream(self.comm):
-                self.comm.wait_event(done)
-                if _active(self.group):
-                    td.all_reduce(P, op=td.ReduceOp.SUM, group=self.group)    # RCCL, ordered on this stream
-                eng.step_apply(P, w, self.A[c], self.B[c], self.A[n], self.B[n])
-                self.ready = torch.cuda.Event()
-                self.ready.record(self.comm)
+        A_old, B_old, A_new, B_new, group = self.A[c], self.B[c], self.A[n], self.B[n], self.group
+
+        def exchange():
+            if _active(group):
+                all_reduce_sum(P, group)          # RCCL: ordered on the stream it is issued on
+            eng.step_apply(P, w, A_old, B_old, A_new, B_new)
+
+        self.ready = self.sched.after_main(exchange)
         self.cur = n
         return H
 

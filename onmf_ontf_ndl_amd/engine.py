@@ -179,8 +179,9 @@ class Engine:
         if tuple(A.shape) != (r, r) or tuple(B.shape) != (r, d):
             raise ValueError("update_dict: A must be (r,r) and B (r,d)")
         W1 = self.empty(d, r) if out is None else out
-        if tuple(W1.shape) != (d, r) or not W1.is_contiguous():
-            raise ValueError("update_dict: out must be a contiguous (d,r) tensor")
+        if tuple(W1.shape) != (d, r) or not W1.is_contiguous() or W1.device != self.device or \
+                W1.dtype != self.torch.float32:
+            raise ValueError("update_dict: out must be a contiguous float32 (d,r) tensor on %s" % self.device)
         rc = self.lib.onmf_update_dict(self.ctx, d, r, _ptr(W), _ptr(A), _ptr(B), _ptr(W1),
                                        self.stream())
         _lib.check(rc, self.ctx, "onmf_update_dict")
@@ -196,6 +197,9 @@ class Engine:
         if tuple(A.shape) != (r, r) or tuple(B.shape) != (r, d):
             raise ValueError("update_dict: A must be (r,r) and B (r,d)")
         W1 = self.empty(d, r) if out is None else out
+        if tuple(W1.shape) != (d, r) or not W1.is_contiguous() or W1.device != self.device or \
+                W1.dtype != self.torch.float32:
+            raise ValueError("update_dict_static: out must be a contiguous float32 (d,r) tensor on %s" % self.device)
         rc = self.lib.onmf_update_dict_static(self.ctx, d, r, _ptr(W), _ptr(A), _ptr(B), _ptr(W1), self.stream())
         _lib.check(rc, self.ctx, "onmf_update_dict_static")
         return W1

@@ -145,19 +145,26 @@ class Image_Reconstructor():
 
     def image_to_patches(self, path, patch_size=7, iterations=500, batch_size=20, color=False, downscale_factor=2,
                          is_matrix=False, is_recons=False):
-        """Grey image -> (k^2 x n) patch matrix (image_reconstruction.py:117-171): every window when
+        """Image -> (k^2 x n) patch matrix (image_reconstruction.py:117-171): every window when
         ``is_recons`` (their order matters for putting them back), else ``iterations*batch_size`` random
         ones drawn the way sklearn's ``extract_patches_2d(max_patches=...)`` draws them."""
-        if color:
-            raise NotImplementedError("image_to_patches: the unfolded-colour branch of the reference "
-                                      "(image_reconstruction.py:139-142) is not carried over")
-        data = _to_numpy(self.read_img_as_array(path, is_matrix=is_matrix, is_color=False))
+        data = _to_numpy(self.read_img_as_array(path, is_matrix=is_matrix, is_color=bool(color)))
+        if color and not is_matrix:
+            # the reference unfolds the RGB image along its channel mode and transposes
+            # (image_reconstruction.py:139-142: tl_unfold(img, mode=2).T): an (h*w) x 3 matrix, whose
+            # windows are then taken like a grey image's - only patch sizes up to 3 fit into it
+            if data.ndim != 3:
+                raise ValueError("image_to_patches(color=True) needs an (h, w, channels) image")
+            data = np.reshape(np.moveaxis(data, 2, 0), (data.shape[2], -1)).T
         if downscale_factor > 1:
             data = downscale_local_mean(data, (downscale_factor, downscale_factor))
         eng = self._engine()
         img = eng.dev(data)
         h, w = data.shape[0], data.shape[1]
         k = patch_size
+        if k > h or k > w:
+            # (scikit-learn's extract_patches_2d refuses the same way)
+            raise ValueError("image_to_patches: patch size %d does not fit into the %d x %d array" % (k, h, w))
         all_patches = (h - k + 1) * (w - k + 1)
         if is_recons or iterations * batch_size >= all_patches:
             X = eng.extract_patches(img, k, grid=(h - k + 1, w - k + 1), stride=1)

@@ -82,6 +82,142 @@ def _worker(rank, world, init_file, out_dir):
         td.destroy_process_group()
 
 
+class OracleStepEngine:
+    """Stands in for ``Engine`` under ``ShardedStepper``: the two entry points it drives, on host tensors, with
+    the oracle's arithmetic.  ``state_ready_event`` is honoured the way the library does: the code solve and the
+    dictionary's own input W are touched at once, A, B and P only after the event."""
+
+    device = torch.device("cpu")
+
+    def __init__(self):
+        from oracle import onmf_oracle as orc
+        self.orc = orc
+        self.log = []
+
+    def empty(self, *shape):
+        return torch.full(shape, float("nan"), dtype=torch.float64)
+
+    def zeros(self, *shape):
+        return torch.zeros(*shape, dtype=torch.float64)
+
+    def partial_floats(self, d, r):
+        return ((r * r + 3) & ~3) + r * d
+
+    def step_partial(self, X, A, B, W, P, W_out=None, alpha=0.0, H0=None, seed=None, sub_iter=10, stopping_diff=0.0,
+                     want_code=True, state_ready_event=None):
+        r, d = B.shape
+        H = self.orc.code_sweeps(X.numpy(), W.numpy(), H0=H0.numpy(), alpha=alpha, sub_iter=sub_iter,
+                                 stopping_diff=-1.0)
+        if state_ready_event is not None:
+            state_ready_event.synchronize()
+        assert not torch.isnan(A).any() and not torch.isnan(B).any(), "aggregates read before they were final"
+        P[:r * r] = torch.from_numpy(H @ H.T).reshape(-1)
+        P[(r * r + 3) & ~3:] = torch.from_numpy(H @ X.numpy().T).reshape(-1)
+        W_out.copy_(torch.from_numpy(self.orc.dictionary_pass(W.numpy(), A.numpy(), B.numpy())))
+        return torch.from_numpy(H), W_out, sub_iter
+
+    def step_apply(self, P, w, A, B, A_out=None, B_out=None):
+        r, d = B.shape
+        A_out.copy_((1.0 - w) * A + w * P[:r * r].view(r, r))
+        B_out.copy_((1.0 - w) * B + w * P[(r * r + 3) & ~3:].view(r, d))
+        return A_out, B_out
+
+
+class LazyExchange:
+    """An exchange scheduler whose work runs as late as the program allows: only when somebody waits for its
+    event - what a slow communication stream looks like to the buffers."""
+
+    class Event:
+        def __init__(self, fn):
+            self.fn = fn
+
+        def synchronize(self):
+            if self.fn is not None:
+                fn, self.fn = self.fn, None
+                fn()
+
+    def __init__(self):
+        self.pending = None
+
+    def after_main(self, fn):
+        prev = self.pending                     # one stream: exchanges complete in the order they were issued
+
+        def chained():
+            if prev is not None:
+                prev.synchronize()
+            fn()
+        self.pending = LazyExchange.Event(chained)
+        return self.pending
+
+    def sync_main(self):
+        pass
+
+
+def _chain_reference(orc, Xs, H0s, W, A, B, t0):
+    for k, (X, H0) in enumerate(zip(Xs, H0s)):
+        _, (A, B), W, _ = orc.minibatch_step(X, [A, B], W, t0 + k, H0=H0, sub_iter=10, stopping_diff=-1.0)
+    return W, A, B
+
+
+def test_sharded_stepper_buffer_rotation_with_a_late_exchange():
+    """Four chained steps through ShardedStepper with every exchange delayed until the library would wait for
+    it: the two buffer sets must keep what a pending exchange still reads, and the result must equal the
+    reference's chain (single rank: the sums are the whole batch's)."""
+    from oracle import onmf_oracle as orc
+    rs = np.random.RandomState(5)
+    d, r, n, steps = 10, 3, 14, 4
+    Xs = [rs.rand(d, n) for _ in range(steps)]
+    H0s = [rs.rand(r, n) for _ in range(steps)]
+    W = rs.rand(d, r)
+    A = rs.rand(r, r); A = A @ A.T
+    B = rs.rand(r, d)
+    for sched in (LazyExchange(), None):
+        st = odist.ShardedStepper(OracleStepEngine(), torch.from_numpy(W), torch.from_numpy(A), torch.from_numpy(B),
+                                  sched=sched)
+        for k in range(steps):
+            st.step(torch.from_numpy(Xs[k]), 1.0 / (3 + k), H0=torch.from_numpy(H0s[k]))
+        W1, A1, B1 = st.state()
+        Wr, Ar, Br = _chain_reference(orc, Xs, H0s, W, A, B, 3)
+        np.testing.assert_allclose(W1.numpy(), Wr, rtol=1e-10, atol=1e-14)
+        np.testing.assert_allclose(A1.numpy(), Ar, rtol=1e-10)
+        np.testing.assert_allclose(B1.numpy(), Br, rtol=1e-10)
+
+
+def _stepper_worker(rank, world, init_file, out_dir):
+    import torch.distributed as td
+    from oracle import onmf_oracle as orc
+    td.init_process_group("gloo", init_method="file://" + init_file, rank=rank, world_size=world)
+    try:
+        rs = np.random.RandomState(11)                       # the same stream on every rank
+        d, r, n, steps = 9, 3, 17, 3
+        Xs = [rs.rand(d, n) for _ in range(steps)]
+        H0s = [rs.rand(r, n) for _ in range(steps)]
+        W = rs.rand(d, r)
+        A = rs.rand(r, r); A = A @ A.T
+        B = rs.rand(r, d)
+        lo, hi = odist.split_columns(n, rank, world)
+        st = odist.ShardedStepper(OracleStepEngine(), torch.from_numpy(W), torch.from_numpy(A), torch.from_numpy(B))
+        for k in range(steps):
+            st.step(torch.from_numpy(Xs[k][:, lo:hi].copy()), 1.0 / (3 + k), H0=torch.from_numpy(H0s[k][:, lo:hi].copy()))
+        W1, A1, B1 = st.state()
+        Wr, Ar, Br = _chain_reference(orc, Xs, H0s, W, A, B, 3)
+        np.testing.assert_allclose(W1.numpy(), Wr, rtol=1e-10, atol=1e-14)
+        np.testing.assert_allclose(A1.numpy(), Ar, rtol=1e-10)
+        np.testing.assert_allclose(B1.numpy(), Br, rtol=1e-10)
+        open(os.path.join(out_dir, "ok%d" % rank), "w").write("ok")
+    finally:
+        td.destroy_process_group()
+
+
+def test_two_rank_gloo_sharded_stepper_against_the_whole_batch():
+    """ShardedStepper over two ranks (columns split, sums all-reduced every step, state replicated) equals the
+    reference's chain on the concatenated batches."""
+    with tempfile.TemporaryDirectory() as tmp:
+        init_file = os.path.join(tmp, "rdzv")
+        mp.spawn(_stepper_worker, args=(2, init_file, tmp), nprocs=2, join=True)
+        assert os.path.exists(os.path.join(tmp, "ok0")) and os.path.exists(os.path.join(tmp, "ok1"))
+
+
 def test_two_rank_gloo_average_and_partial_sums():
     with tempfile.TemporaryDirectory() as tmp:
         init_file = os.path.join(tmp, "rdzv")

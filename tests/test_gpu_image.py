@@ -244,3 +244,29 @@ def test_tensor_reconstructor_trains_along_a_mode(eng):
                               num_patches=30, patch_size=3, is_color=True)
     W = rec.train_dict(mode=2, learn_joint_dict=True)
     assert W.shape == (27, 5) and W.min() >= 0 and np.linalg.norm(W, axis=0).max() <= 1 + 1e-5
+
+
+def test_image_to_patches_grey_and_unfolded_colour_against_sklearn(eng):
+    """image_to_patches (image_reconstruction.py:117-171) for reconstruction (every window, in order): the grey
+    branch, and the colour branch, which unfolds the RGB image along its channel mode and transposes it
+    (tl_unfold(img, mode=2).T, :139-142) before the windows are taken - against scikit-learn's
+    extract_patches_2d on the same matrices."""
+    from sklearn.feature_extraction.image import extract_patches_2d
+    from onmf_ontf_ndl_amd.image_reconstruction import Image_Reconstructor, downscale_local_mean
+    rs = np.random.RandomState(41)
+    grey = rs.rand(18, 14).astype(np.float32).astype(np.float64)
+    rec = Image_Reconstructor(grey, n_components=4, patch_size=5, is_color=False)
+    X = rec.image_to_patches(grey, patch_size=5, downscale_factor=2, is_recons=True)
+    small = downscale_local_mean(grey, (2, 2))
+    want = extract_patches_2d(small, (5, 5))
+    want = want.reshape(len(want), -1).T
+    assert X.shape == want.shape and relerr(X, want) < 1e-7
+    rgb = rs.rand(9, 7, 3).astype(np.float32).astype(np.float64)
+    rec = Image_Reconstructor(rgb, n_components=4, patch_size=2, is_color=True)
+    X = rec.image_to_patches(rgb, patch_size=2, color=True, downscale_factor=1, is_recons=True)
+    unfolded = np.reshape(np.moveaxis(rgb, 2, 0), (3, -1)).T            # (h*w) x 3
+    want = extract_patches_2d(unfolded, (2, 2))
+    want = want.reshape(len(want), -1).T
+    assert X.shape == want.shape == (4, (9 * 7 - 1) * 2) and np.array_equal(X, want)
+    with pytest.raises(ValueError):
+        rec.image_to_patches(rgb, patch_size=7, color=True, downscale_factor=1, is_recons=True)

@@ -62,3 +62,26 @@ def test_static_entry_rejects_sizes_beyond_its_array():
         assert b"static scratch" in eng.lib.onmf_last_error(eng.ctx)
         with pytest.raises(_lib.OnmfLibraryError):
             eng.update_dict_static(W, A, B)
+
+
+def test_static_entry_calls_from_two_streams_are_ordered_on_the_gpu():
+    """Two calls on two streams share the GPU's one scratch array: the library orders the second behind the
+    first (an event per device), so both give what onmf_update_dict gives."""
+    import torch
+    from onmf_ontf_ndl_amd.engine import get_engine
+    eng = get_engine()
+    rs = np.random.RandomState(321)
+    cases = [_state(rs, 1024, 256), _state(rs, 900, 200)]
+    devs = [tuple(eng.dev(x) for x in c) for c in cases]
+    outs = [eng.empty(1024, 256), eng.empty(900, 200)]
+    streams = [torch.cuda.Stream(device=eng.device), torch.cuda.Stream(device=eng.device)]
+    torch.cuda.synchronize()
+    for rep in range(3):
+        for (W, A, B), out, st in zip(devs, outs, streams):
+            with torch.cuda.stream(st):
+                eng.update_dict_static(W, A, B, out=out)
+    torch.cuda.synchronize()
+    for (W, A, B), out in zip(devs, outs):
+        assert torch.equal(out, eng.update_dict(W, A, B))
+    with pytest.raises(ValueError):
+        eng.update_dict_static(*devs[0], out=eng.empty(256, 1024))

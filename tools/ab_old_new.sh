@@ -9,8 +9,9 @@ line() {   # label, bench arguments...
     timeout -k 10 200 python3 bench.py --no-cpu-baseline --no-also --no-parity "$@" 2>>$O/err.txt | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$label', '$*', round(d['ms_per_step'], 4), round(d.get('roofline', {}).get('achieved', 0), 2))" >> $O/res.txt || exit 1
 }
 : > $O/res.txt
-cp onmf_ontf_ndl_amd/libonmf_hip.so /tmp/new.so
-use() { if [ "$1" = new ]; then cp /tmp/new.so onmf_ontf_ndl_amd/libonmf_hip.so; else cp tools/probe/libonmf_hip_old.so onmf_ontf_ndl_amd/libonmf_hip.so; fi; }
+# the build to measure is chosen through ONMF_HIP_LIB (read by onmf_ontf_ndl_amd/_lib.py); the product library
+# in the package directory is never overwritten
+use() { if [ "$1" = new ]; then unset ONMF_HIP_LIB; else export ONMF_HIP_LIB=$PWD/tools/probe/libonmf_hip_old.so; fi; }
 use new; timeout -k 10 200 python3 tools/hash_solve.py > $O/hash_new.txt 2>>$O/err.txt || exit 1
 use old; timeout -k 10 200 python3 tools/hash_solve.py > $O/hash_old.txt 2>>$O/err.txt || exit 1
 for rep in 1 2 3; do
