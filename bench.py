@@ -178,9 +178,10 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
-def launch_ranks(n, argv):
-    """Start n copies of this script, one rank each, and wait for them.  Runs before anything in this
-    process has touched a GPU (nothing here imports torch)."""
+def launch_ranks(n, argv, script=None):
+    """Start n copies of this script (or ``script``), one rank each, and wait for them.  Runs before anything
+    in this process has touched a GPU (nothing here imports torch).  Returns the first non-zero exit code of
+    a rank (the other ranks are then terminated: they would wait for it forever), else 0."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -188,7 +189,7 @@ def launch_ranks(n, argv):
     for rank in range(n):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(script or __file__)] + list(argv), env=env))
     rc = 0
     pending = list(procs)
     while pending:
@@ -223,6 +224,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU path)")
     torch.cuda.set_device(local)
+    pinned = odist.pin_to_local_cores(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)), local) if world > 1 else None
     eng = get_engine(torch.device("cuda", local))
     for kv in args.opt:
         key, value = kv.split("=")
@@ -323,7 +325,8 @@ def main():
                    "step_frac_of_fp32_mfma_peak": flops / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS}
         if world > 1:
             cfg.update({"multi_gpu_mode": args.mode, "backend": backend,
-                        "sync_every": args.sync_every if stepper is None else 1})
+                        "sync_every": args.sync_every if stepper is None else 1,
+                        "rank0_cpu_cores": len(pinned) if pinned else None})
         cfg["recovery_counters"] = eng.counters()
         out = {
             "metric": "patches/sec per ONMF minibatch step (d x r dict)",

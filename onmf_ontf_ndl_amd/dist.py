@@ -55,6 +55,69 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
+def parse_cpulist(text):
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11] (the format of /sys/devices/system/node/node*/cpulist)."""
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        out.extend(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def share_of_cores(cores, position, sharers):
+    """The ``position``-th of ``sharers`` contiguous, near-equal shares of ``cores`` (never empty)."""
+    cores = sorted(cores)
+    if sharers <= 1 or len(cores) < sharers:
+        return cores
+    base, extra = divmod(len(cores), sharers)
+    lo = position * base + min(position, extra)
+    return cores[lo:lo + base + (1 if position < extra else 0)]
+
+
+def _gpu_numa_node(index):
+    """NUMA node of GPU ``index`` from sysfs, or None."""
+    try:
+        import torch
+        p = torch.cuda.get_device_properties(index)
+        bdf = "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+        with open("/sys/bus/pci/devices/%s/numa_node" % bdf) as f:
+            node = int(f.read().strip())
+        return node if node >= 0 else None
+    except Exception:
+        return None
+
+
+def pin_to_local_cores(local_rank, local_world, device_index=None):
+    """Keep this rank's process on cores of its own: the cores of its GPU's NUMA node that the process may
+    use, shared out among the ranks whose GPUs sit on the same node; an even share of the allowed cores when
+    the topology cannot be read.  The small shapes are bound by the host's launch rate, which suffers when
+    eight ranks' threads wander over two sockets.  Returns the cores chosen, or None where the platform has
+    no ``sched_setaffinity``."""
+    if not hasattr(os, "sched_setaffinity"):
+        return None
+    allowed = sorted(os.sched_getaffinity(0))
+    chosen = None
+    node = _gpu_numa_node(device_index) if device_index is not None else None
+    if node is not None:
+        try:
+            with open("/sys/devices/system/node/node%d/cpulist" % node) as f:
+                local_cores = [c for c in parse_cpulist(f.read()) if c in set(allowed)]
+            mates = [k for k in range(local_world) if _gpu_numa_node(k) == node]
+            if local_cores and local_rank in mates:
+                chosen = share_of_cores(local_cores, mates.index(local_rank), len(mates))
+        except (OSError, ValueError):
+            chosen = None
+    if not chosen:
+        chosen = share_of_cores(allowed, local_rank % max(1, local_world), local_world)
+    try:
+        os.sched_setaffinity(0, chosen)
+    except OSError:
+        return None
+    return chosen
+
+
 def _active(group=None):
     import torch.distributed as td
     return td.is_available() and td.is_initialized()
@@ -109,6 +172,11 @@ def average_state_(state, group=None, force=False):
         return state
     world = td.get_world_size(group)
     if world == 1 and not force:
+        return state
+    if state.flat.is_cuda and td.get_backend(group) == "nccl":
+        # RCCL averages in the collective itself: one operation on the buffer, ordered on the current
+        # stream (torch runs it on its communicator's stream between two events; the host does not wait)
+        td.all_reduce(state.flat, op=td.ReduceOp.AVG, group=group)
         return state
     all_reduce_sum(state.flat, group)
     if world > 1:

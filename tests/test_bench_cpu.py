@@ -48,3 +48,50 @@ def test_a_process_group_of_another_size_is_refused(tmp_path):
                          env=env, capture_output=True, text=True, timeout=300)
     assert res.returncode != 0 and "refusing" in res.stderr
     assert not any(line.startswith("{") for line in res.stdout.splitlines())
+
+
+STUB = '''import json, os, sys, time
+rank = int(os.environ["RANK"])
+with open(os.path.join(sys.argv[1], "env%d.json" % rank), "w") as f:
+    json.dump({k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE",
+                                              "MASTER_ADDR", "MASTER_PORT")}, f)
+mode = sys.argv[2]
+if mode == "fail" and rank == 1:
+    sys.exit(7)
+if mode == "fail":
+    time.sleep(60)          # a rank that would wait for the failed one forever
+'''
+
+
+def test_launch_ranks_hands_every_child_its_rank_and_returns_the_first_failure(tmp_path):
+    """bench.launch_ranks with a stub script: environment per child; when one rank fails, the others are
+    terminated and its exit code becomes the launcher's."""
+    import time
+    import bench
+    stub = tmp_path / "stub.py"
+    stub.write_text(STUB)
+    assert bench.launch_ranks(3, [str(tmp_path), "ok"], script=str(stub)) == 0
+    envs = [json.load(open(tmp_path / ("env%d.json" % k))) for k in range(3)]
+    assert [e["RANK"] for e in envs] == ["0", "1", "2"] and [e["LOCAL_RANK"] for e in envs] == ["0", "1", "2"]
+    assert all(e["WORLD_SIZE"] == "3" and e["LOCAL_WORLD_SIZE"] == "3" and e["MASTER_ADDR"] == "127.0.0.1" for e in envs)
+    assert len({e["MASTER_PORT"] for e in envs}) == 1
+    t0 = time.time()
+    assert bench.launch_ranks(3, [str(tmp_path), "fail"], script=str(stub)) == 7
+    assert time.time() - t0 < 30          # the sleeping ranks were terminated, not waited for
+
+
+def test_core_shares_for_rank_pinning():
+    from onmf_ontf_ndl_amd import dist as odist
+    assert odist.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    cores = list(range(96))
+    shares = [odist.share_of_cores(cores, k, 4) for k in range(4)]
+    assert [len(s) for s in shares] == [24] * 4 and sorted(sum(shares, [])) == cores
+    assert odist.share_of_cores([5, 1, 3], 1, 2) == [5]                 # sorted, near-equal, never empty
+    assert odist.share_of_cores([0, 1], 0, 8) == [0, 1]                 # fewer cores than ranks: all of them
+    if hasattr(os, "sched_setaffinity"):
+        before = os.sched_getaffinity(0)
+        try:
+            got = odist.pin_to_local_cores(1, 2, None)
+            assert got and set(got) <= before and os.sched_getaffinity(0) == set(got)
+        finally:
+            os.sched_setaffinity(0, before)
