@@ -300,6 +300,23 @@ int onmf_ndl_sample_patches(onmf_ctx* ctx, int n_nodes, const int32_t* row_ptr, 
 int onmf_ndl_accumulate_edges(onmf_ctx* ctx, int n_nodes, int k, int n_patches, const int32_t* emb_trace,
                               const float* R, int ldr, float* sum, float* count, void* stream);
 
+/*
+ * np.random.rand(n) out of NumPy's legacy global generator (MT19937), continued on the device: the draw the
+ * reference makes for the start code of every solve, H0 = np.random.rand(r, b) (src/onmf.py:245-246; also
+ * the initial dictionary, :190), written to device memory as float32 - the float64 value NumPy would
+ * return, rounded once.
+ *   key, pos      HOST: the generator's 624 state words and position, as np.random.get_state() gives them
+ *   key_out, pos_out  HOST: the state after the draw, for np.random.set_state() - the host's stream goes on
+ *                 exactly where NumPy would be after np.random.rand(n)
+ * Synchronises `stream` (it returns host data).  With a jump table (onmf_numpy_set_jump_table: rows j = 1..n
+ * hold x^(j * chunk_words - 1) modulo the generator's minimal polynomial, 624 words each, computed by
+ * onmf_ontf_ndl_amd/mt_jump.py) chunks of chunk_words = 262 080 stream words are produced by as many
+ * workgroups at once; without one, chunk after chunk by a single workgroup.  Same output either way.
+ */
+int onmf_numpy_set_jump_table(onmf_ctx* ctx, const uint32_t* table_host, int rows, long long chunk_words);
+int onmf_numpy_rand(onmf_ctx* ctx, const uint32_t* key, int pos, size_t n, float* out, uint32_t* key_out,
+                    int* pos_out, void* stream);
+
 /* U[0,1) fill, the device stand-in for np.random.rand (src/onmf.py:190, :246). */
 int onmf_fill_uniform(onmf_ctx* ctx, float* out, size_t n, uint64_t seed, void* stream);
 

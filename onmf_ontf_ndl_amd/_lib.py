@@ -87,6 +87,9 @@ SIGNATURES = {
                                           C.c_void_p, C.c_void_p]),
     "onmf_ndl_accumulate_edges": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, C.c_void_p, _f, C.c_int, _f, _f,
                                             C.c_void_p]),
+    "onmf_numpy_set_jump_table": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_longlong]),
+    "onmf_numpy_rand": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_size_t, _f, C.c_void_p, C.POINTER(C.c_int),
+                                  C.c_void_p]),
     "onmf_fill_uniform": (C.c_int, [_ctx, _f, C.c_size_t, C.c_uint64, C.c_void_p]),
     "onmf_host_lambda_max": (C.c_double, [C.c_void_p, C.c_int]),
     "onmf_set_option": (C.c_int, [_ctx, C.c_int, C.c_int]),

@@ -164,7 +164,7 @@ int onmf_destroy(onmf_ctx* c) {
     (void)hipDeviceSynchronize();
     DevBuf* bufs[] = {&c->slab, &c->cm, &c->gram, &c->hbuf[0], &c->hbuf[1], &c->stats, &c->small,
                       &c->qt, &c->sync, &c->idx, &c->dbuf, &c->slab_side, &c->screen, &c->ddelta, &c->slab_prep,
-                      &c->gstack, &c->rslab, &c->gram64, &c->cm64, &c->lars_ws, &c->lars_meta, &c->lars_overflow};
+                      &c->gstack, &c->rslab, &c->gram64, &c->cm64, &c->lars_ws, &c->lars_meta, &c->lars_overflow, &c->mt};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (c->pinned) (void)hipHostFree(c->pinned);
@@ -1259,6 +1259,25 @@ int onmf_ndl_accumulate_edges(onmf_ctx* c, int n_nodes, int k, int n_patches, co
     if (launch_ndl_edge_accumulate(n_nodes, k, n_patches, emb_trace, R, ldr, sum, count, (hipStream_t)stream) != ONMF_OK)
         return onmf_fail(c, ONMF_ERR_HIP, "ndl_accumulate_edges: launch failed");
     return ONMF_OK;
+}
+
+int onmf_numpy_set_jump_table(onmf_ctx* c, const uint32_t* table_host, int rows, long long chunk_words) {
+    if (!c) return ONMF_ERR_ARG;
+    if (rows < 0 || rows > 4096 || (rows > 0 && !table_host) || chunk_words != numpy_rand_chunk_words())
+        return onmf_fail(c, ONMF_ERR_ARG, "numpy_set_jump_table: %d rows for chunks of %lld words (the kernels' "
+                         "chunk is %lld words)", rows, chunk_words, numpy_rand_chunk_words());
+    ONMF_ENTER(c);
+    return numpy_rand_setup(c, table_host, rows, nullptr);
+}
+
+int onmf_numpy_rand(onmf_ctx* c, const uint32_t* key, int pos, size_t n, float* out, uint32_t* key_out, int* pos_out,
+                    void* stream) {
+    if (!c) return ONMF_ERR_ARG;
+    if (!key || !key_out || !pos_out || pos < 0 || pos > 624 || (n > 0 && !out))
+        return onmf_fail(c, ONMF_ERR_ARG, "numpy_rand: bad arguments (pos=%d)", pos);
+    ONMF_ENTER(c);
+    if (c->mt_rows < 0) ONMF_TRY(numpy_rand_setup(c, nullptr, 0, (hipStream_t)stream));
+    return launch_numpy_rand(c, key, pos, n, out, key_out, pos_out, (hipStream_t)stream);
 }
 
 int onmf_fill_uniform(onmf_ctx* c, float* out, size_t n, uint64_t seed, void* stream) {

@@ -84,6 +84,9 @@ struct onmf_ctx {
     DevBuf gram64, cm64, lars_ws, lars_meta, lars_overflow;
     bool lars_hint_ok = false;            // a LARS call of this context has published its slot count
     int lars_slots = 0;                   // ONMF_OPT_LARS_SLOTS
+    // NumPy's MT19937 stream on the device (mt19937.hip): jump table, head words, chunk blocks, final block
+    DevBuf mt;
+    int mt_rows = -1;                     // rows of the jump table held (-1: buffers not set up)
 };
 
 // Makes the context's device current for the duration of an entry point and puts the caller's back
@@ -448,6 +451,11 @@ int launch_prod_f64(onmf_ctx* c, int M, int N, int K, const float* A, int lda, c
 int launch_lars_pos(onmf_ctx* c, int r, int b, const double* G, const double* Cd, int ldc, double alpha,
                     double n_samples, int max_iter, float* H, int ldh, int* info, hipStream_t s);
 
+// np.random.rand(n) continued on the device from NumPy's (key, pos); see mt19937.hip.  Synchronises s.
+int launch_numpy_rand(onmf_ctx* c, const uint32_t* key_host, int pos, size_t n, float* out, uint32_t* key_out_host,
+                      int* pos_out, hipStream_t s);
+int numpy_rand_setup(onmf_ctx* c, const uint32_t* table_host, int rows, hipStream_t s);
+long long numpy_rand_chunk_words();
 int launch_fill_uniform(float* out, size_t n, uint64_t seed, hipStream_t s);
 int launch_gather_columns(int d, int n, const float* X, int ldx, const long long* idx, int b,
                           float* Xb, hipStream_t s);

@@ -50,6 +50,7 @@ class Engine:
         self.ctx = ctx
         self._seed_counter = 0
         self._timeouts_seen = 0
+        self._mt_table_set = False
 
     def __del__(self):
         try:
@@ -446,6 +447,35 @@ class Engine:
                                                 _ptr(total), _ptr(count), self.stream())
         _lib.check(rc, self.ctx, "onmf_ndl_accumulate_edges")
         return total, count
+
+    NUMPY_RAND_ON_DEVICE_FROM = 32768       # smaller draws: NumPy itself and one upload are as quick
+
+    def numpy_rand(self, rows, cols):
+        """``np.random.rand(rows, cols)`` as a float32 tensor on this GPU, drawn out of NumPy's global legacy
+        generator (the reference's H0 and initial dictionary, src/onmf.py:245-246, :190): the generator's state
+        goes to the device, the draw is made there (onmf_numpy_rand), and NumPy gets the advanced state back -
+        the host's random stream continues exactly as if NumPy had made the draw.  Bit-identical to
+        ``dev(np.random.rand(rows, cols))``."""
+        n = int(rows) * int(cols)
+        state = np.random.get_state()
+        if n < self.NUMPY_RAND_ON_DEVICE_FROM or state[0] != "MT19937":
+            return self.dev(np.random.rand(rows, cols))
+        if not self._mt_table_set:
+            from . import mt_jump
+            table = np.ascontiguousarray(mt_jump.load_table(), dtype=np.uint32)
+            rc = self.lib.onmf_numpy_set_jump_table(self.ctx, table.ctypes.data_as(C.c_void_p), table.shape[0],
+                                                    mt_jump.CHUNK_WORDS)
+            _lib.check(rc, self.ctx, "onmf_numpy_set_jump_table")
+            self._mt_table_set = True
+        key = np.ascontiguousarray(state[1], dtype=np.uint32)
+        key_out = np.empty(624, dtype=np.uint32)
+        pos_out = C.c_int(0)
+        out = self.empty(rows, cols)
+        rc = self.lib.onmf_numpy_rand(self.ctx, key.ctypes.data_as(C.c_void_p), int(state[2]), n, _ptr(out),
+                                      key_out.ctypes.data_as(C.c_void_p), C.byref(pos_out), self.stream())
+        _lib.check(rc, self.ctx, "onmf_numpy_rand")
+        np.random.set_state(("MT19937", key_out, int(pos_out.value), state[3], state[4]))
+        return out
 
     def rand(self, rows, cols, seed=None):
         out = self.empty(rows, cols)

@@ -116,7 +116,7 @@ class Online_NMF():
 
     def _draw_h0(self, eng, r, b):
         if self.rng == "numpy":
-            return eng.dev(np.random.rand(r, b)), None      # src/onmf.py:245-246
+            return eng.numpy_rand(r, b), None               # src/onmf.py:245-246
         return None, eng.next_seed(self.seed)
 
     # -- reference API ----------------------------------------------------------------------
@@ -174,7 +174,7 @@ class Online_NMF():
 
         if self.initial_dict is None:
             if self.rng == "numpy":
-                Wd = eng.dev(np.random.rand(d, r))          # src/onmf.py:190
+                Wd = eng.numpy_rand(d, r)                   # src/onmf.py:190
             else:
                 Wd = eng.rand(d, r, eng.next_seed(self.seed))
             Ad, Bd = eng.zeros(r, r), eng.zeros(r, d)
@@ -235,9 +235,8 @@ def update_code_within_radius(X, W, H0=None, r=None, alpha=0, sub_iter=10, stopp
     eng = get_engine(device)
     like_torch = _is_torch(X)
     Xd, Wd = eng.dev(X), eng.dev(W)
-    if H0 is None:
-        H0 = np.random.rand(Wd.shape[1], Xd.shape[1])       # src/onmf.py:245-246
-    H, sweeps, dist = eng.sparse_code(Xd, Wd, H0=eng.dev(H0), alpha=alpha, sub_iter=sub_iter,
+    H0 = eng.numpy_rand(Wd.shape[1], Xd.shape[1]) if H0 is None else eng.dev(H0)       # src/onmf.py:245-246
+    H, sweeps, dist = eng.sparse_code(Xd, Wd, H0=H0, alpha=alpha, sub_iter=sub_iter,
                                       stopping_diff=stopping_diff, radius=r)
     out = _out(H, like_torch)
     return (out, sweeps, dist) if return_info else out

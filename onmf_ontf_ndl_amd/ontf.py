@@ -146,7 +146,7 @@ class Online_NTF():
         r = self.n_components
         if self.initial_dict is None:
             if self.rng == "numpy":
-                Wd = eng.dev(np.random.rand(d, r))           # src/ontf.py:213
+                Wd = eng.numpy_rand(d, r)                    # src/ontf.py:213
             else:
                 Wd = eng.rand(d, r, eng.next_seed(self.seed))
             if DEBUG:
