@@ -47,6 +47,20 @@ for d, r, b, n in ((100, 16, 1000, 60), (1024, 64, 8192, 30), (1024, 256, 65536,
         Ad, Bd = aggd
     torch.cuda.synchronize()
     devt = (time.perf_counter() - t0) / n
+    # device tensors in and out, H0 from NumPy's own stream (drawn on the device out of NumPy's state)
+    nmf_np = Online_NMF(X, n_components=r, iterations=2, batch_size=b, rng="numpy")
+    nmf_np.step(Xd, [Ad, Bd], Wd, 1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(n):
+        Hd, aggd, Wd = nmf_np.step(Xds[t % 3], [Ad, Bd], Wd, t + 2)
+        Ad, Bd = aggd
+    torch.cuda.synchronize()
+    devt_np = (time.perf_counter() - t0) / n
+    t0 = time.perf_counter()
+    h0d = eng.numpy_rand(r, b)
+    torch.cuda.synchronize()
+    draw_dev = time.perf_counter() - t0
     t0 = time.perf_counter()
     x32 = torch.from_numpy(X).to(eng.device, torch.float32)
     torch.cuda.synchronize()
@@ -56,5 +70,8 @@ for d, r, b, n in ((100, 16, 1000, 60), (1024, 64, 8192, 30), (1024, 256, 65536,
     down = time.perf_counter() - t0
     print("d=%d r=%d b=%d: NumPy float64 in/out, H0 from NumPy's generator (the reference's stream) %.2f ms per step "
           "(%.2f M patches/s); the same with rng='device' %.2f ms; device tensors in/out, rng='device' %.2f ms; "
-          "parts: np.random.rand(r, b) %.2f ms, X up %.2f ms, H down and to float64 %.2f ms"
-          % (d, r, b, host * 1e3, b / host / 1e6, host_devrng * 1e3, devt * 1e3, draw * 1e3, up * 1e3, down * 1e3))
+          "device tensors in/out, rng='numpy' (NumPy's stream continued on the device) %.2f ms; "
+          "parts: np.random.rand(r, b) on the host %.2f ms, the same draw on the device %.2f ms, X up %.2f ms, "
+          "H down and to float64 %.2f ms"
+          % (d, r, b, host * 1e3, b / host / 1e6, host_devrng * 1e3, devt * 1e3, devt_np * 1e3, draw * 1e3,
+             draw_dev * 1e3, up * 1e3, down * 1e3))
