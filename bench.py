@@ -172,6 +172,9 @@ def parse_args(argv=None):
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
                     help="library option (ONMF_OPT_* number = value), for experiments")
     ap.add_argument("--cpu-cols", type=int, default=0, help="columns of the CPU-baseline sample (0 = auto)")
+    ap.add_argument("--no-defer", action="store_true",
+                    help="read every step's sweep count (one host wait per step) instead of letting the library look "
+                         "at a step's stopping-test verdicts at the next call (ONMF_OPT_DEFER_VERDICT)")
     ap.add_argument("--coder", default="lars", choices=["lars", "cd"],
                     help="c3-ntf workloads: scikit-learn's positive LARS path (the reference's coder) or exact "
                          "coordinate descent on the same convex problem")
@@ -248,6 +251,9 @@ def main():
     stepper = None
     if world > 1 and args.mode == "sharded":
         stepper = odist.ShardedStepper(eng, state[0].W, state[0].A, state[0].B)
+    defer = not args.no_defer and not ntf and stepper is None
+    if defer:
+        eng.set_option(_lib.OPT_DEFER_VERDICT, 1)
     coder = None
     if ntf:
         from onmf_ontf_ndl_amd import Online_NTF
@@ -269,29 +275,40 @@ def main():
             st, nx = state[cur], state[1 - cur]
             _, _, _, _, _, s, _ = eng.step(X, st.A, st.B, None, st.W, 1.0 / t, alpha=0.0, H0=None,
                                            seed=1000 * rank + t, sub_iter=SWEEPS,
-                                           stopping_diff=args.stopping_diff, want_code=False, out=nx.views())
+                                           stopping_diff=args.stopping_diff, want_code=False, out=nx.views(),
+                                           defer=defer)
         cur = 1 - cur
         t += 1
         if world > 1 and stepper is None and args.sync_every > 0 and (t % args.sync_every) == 0:
+            if defer:
+                eng.settle()         # the exchange reads the step's outputs: they have to be final
             odist.average_state_(state[cur])
         return s
 
     for i in range(max(args.warmup, 0)):
         one_step(i)
+    eng.settle()
     eng.set_option(_lib.OPT_PROFILE, 1)
     eng.get_profile()
+    sweeps_before = eng.counters()["sweeps_total"]
     if world > 1:
         td.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         sweeps_seen.append(one_step(args.warmup + i))
+    eng.settle()                 # (a step that was not waited for is settled inside the timed region)
     torch.cuda.synchronize()
     if world > 1:
         td.barrier()
     elapsed = time.perf_counter() - t0
     sweep_ms, sweep_launches = eng.get_profile()
     eng.set_option(_lib.OPT_PROFILE, 0)
+    if defer:
+        # the steps returned no counts: the library's own total over the timed steps
+        total = eng.counters()["sweeps_total"] - sweeps_before
+        sweeps_seen = [total / max(1, args.steps)] * args.steps
+        eng.set_option(_lib.OPT_DEFER_VERDICT, 0)
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if backend == "gloo" else eng.device)
         td.all_reduce(tt, op=td.ReduceOp.MAX)
@@ -321,6 +338,7 @@ def main():
                                "stopping_diff=%g, device-drawn H0, (A,B,W) carried"
                                % (args.workload, d, r, b, SWEEPS, args.stopping_diff),
                    "mean_sweeps": mean_sweeps,
+                   "host_waits_per_step": 0 if defer else 1,
                    "step_tflops_per_gpu": flops / (ms * 1e-3) / 1e12,
                    "step_frac_of_fp32_mfma_peak": flops / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS}
         if world > 1:

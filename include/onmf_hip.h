@@ -157,6 +157,19 @@ int onmf_step(onmf_ctx* ctx, int d, int r, int b, const float* X, int ldx, const
  * hides that exchange under this step's W^T X and sweeps (legal because the dictionary pass of step t
  * needs the aggregates of step t-1 only).  With stopping_diff > 0 every rank tests its own columns.
  */
+/*
+ * With ONMF_OPT_DEFER_VERDICT set, an onmf_step call that asks for no host scalars (sweeps_done == NULL and
+ * dist_trace == NULL) does not wait for the GPU at all: the sweeps decide the stopping test on the device and
+ * everything behind them is enqueued on the assumption that their verdicts are conclusive.  The host looks at
+ * the verdict records at the NEXT entry point called on the context (or onmf_settle); where a verdict was not
+ * conclusive - the bounds straddled stopping_diff in the middle of the solve - the solve and the aggregate
+ * products are run again there, on `stream`, before anything else.  The caller's side of the bargain: the
+ * call's input buffers stay untouched, and nothing but this library reads its outputs H_out, A_out, B_out,
+ * C_out, until that next entry point has returned.  W_out is final at once (it does not depend on the code).
+ * Same results as without the option.
+ */
+int onmf_settle(onmf_ctx* ctx);
+
 size_t onmf_partial_floats(int d, int r);
 int onmf_step_partial(onmf_ctx* ctx, int d, int r, int b, const float* X, int ldx, const float* W_in,
                       const float* A_in, const float* B_in, const float* H0, uint64_t seed, float alpha,
@@ -362,6 +375,9 @@ double onmf_host_lambda_max(const float* S_host, int n);
  *                          second launch with room for r (ONMF_CNT_LARS_RECODED counts them).  0 (default):
  *                          that rule; n > 0: n slots (at most 64, or r) in the first launch whatever the
  *                          history.  Same codes either way.
+ *   ONMF_OPT_DEFER_VERDICT != 0: onmf_step calls that return no host scalars do not wait for the stopping test's
+ *                          verdicts; see onmf_settle.  0 (default): every call's outputs are final when it returns
+ *                          (in stream order).
  *   ONMF_OPT_SPIN_LIMIT_MS bound, in milliseconds, of the waits of workgroups for each other - a
  *                          one-launch solve's, and the dictionary pass's for d > 1024 (default 2000;
  *                          -1: give up at the first look if what is waited for is not there yet; -2: give
@@ -383,6 +399,7 @@ double onmf_host_lambda_max(const float* S_host, int n);
 #define ONMF_OPT_SPIN_LIMIT_MS 8
 #define ONMF_OPT_DEVICE_RESOLVE 9
 #define ONMF_OPT_LARS_SLOTS 10
+#define ONMF_OPT_DEFER_VERDICT 11
 int onmf_set_option(onmf_ctx* ctx, int key, int value);
 /*
  * Event counters since onmf_create (no counterpart in the reference):
@@ -397,6 +414,8 @@ int onmf_set_option(onmf_ctx* ctx, int key, int value);
 #define ONMF_CNT_DEVICE_RESOLVES 4   /* inconclusive stopping tests settled on the device (no host round trip) */
 #define ONMF_CNT_LARS_RECODED 5      /* columns of onmf_sparse_code_lars coded by its second launch (calls still in
                                         flight are not in the count yet) */
+#define ONMF_CNT_SWEEPS_TOTAL 7       /* sweeps run by all settled solves (what sweeps_done would have summed to) */
+#define ONMF_CNT_DEFERRED_REDONE 8   /* deferred steps (ONMF_OPT_DEFER_VERDICT) whose solve had to be run again */
 #define ONMF_CNT_LARS_SLOTS_USED 6   /* not a count: the most atoms a column of the last completed
                                         onmf_sparse_code_lars call held at a time */
 int onmf_get_counter(onmf_ctx* ctx, int which, long long* value);

@@ -26,12 +26,15 @@ OPT_PERSISTENT_SWEEPS = 7
 OPT_SPIN_LIMIT_MS = 8
 OPT_DEVICE_RESOLVE = 9
 OPT_LARS_SLOTS = 10
+OPT_DEFER_VERDICT = 11
 CNT_SWEEP_TIMEOUTS = 1
 CNT_DICT_TIMEOUTS = 2
 CNT_FALLBACK_SOLVES = 3
 CNT_DEVICE_RESOLVES = 4
 CNT_LARS_RECODED = 5
 CNT_LARS_SLOTS_USED = 6
+CNT_SWEEPS_TOTAL = 7
+CNT_DEFERRED_REDONE = 8
 NDL_GLAUBER = 0
 NDL_PIVOT = 1
 
@@ -58,6 +61,7 @@ SIGNATURES = {
                             C.c_uint64, C.c_double, C.c_float, C.c_int, C.c_float,
                             _f, _f, _f, _f, _f, C.POINTER(C.c_int), C.POINTER(C.c_float),
                             C.c_void_p]),
+    "onmf_settle": (C.c_int, [_ctx]),
     "onmf_partial_floats": (C.c_size_t, [C.c_int, C.c_int]),
     "onmf_step_partial": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, _f, C.c_int, _f, _f, _f, _f, C.c_uint64,
                                     C.c_float, C.c_int, C.c_float, _f, _f, _f, C.POINTER(C.c_int),

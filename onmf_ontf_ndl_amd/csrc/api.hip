@@ -168,6 +168,7 @@ int onmf_destroy(onmf_ctx* c) {
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->rec_pinned) (void)hipHostFree(c->rec_pinned);
     if (c->host_events) (void)hipHostFree(c->host_events);
     for (hipEvent_t ev : c->ev) (void)hipEventDestroy(ev);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -199,6 +200,7 @@ int onmf_set_option(onmf_ctx* c, int key, int value) {
             return ONMF_OK;
         case ONMF_OPT_DEVICE_RESOLVE: c->device_resolve = value; return ONMF_OK;
         case ONMF_OPT_LARS_SLOTS: c->lars_slots = value < 0 ? 0 : value; return ONMF_OK;
+        case ONMF_OPT_DEFER_VERDICT: c->defer_verdict = value; return ONMF_OK;
         case ONMF_OPT_SPIN_LIMIT_MS:
             c->spin_limit = value == -2 ? SPIN_FORCE_TIMEOUT
                                         : value < 0 ? -1LL : (long long)value * 100000LL;      // 100 MHz ticks
@@ -221,6 +223,8 @@ int onmf_get_counter(onmf_ctx* c, int which, long long* value) {
         case ONMF_CNT_LARS_RECODED:
             *value = c->host_events ? ((volatile int*)c->host_events)[ONMF_LARS_HOST_WORDS + 2] : 0;
             return ONMF_OK;
+        case ONMF_CNT_SWEEPS_TOTAL: *value = c->sweeps_total; return ONMF_OK;
+        case ONMF_CNT_DEFERRED_REDONE: *value = c->n_deferred_redone; return ONMF_OK;
         case ONMF_CNT_LARS_SLOTS_USED:
             *value = c->host_events ? ((volatile int*)c->host_events)[ONMF_LARS_HOST_WORDS] : 0;
             return ONMF_OK;
@@ -344,7 +348,11 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
                             int* sweeps_done, float* dist_trace, hipStream_t s,
                             const std::function<int()>* after = nullptr, bool* after_valid = nullptr,
                             bool second_try = false, const std::function<int()>* behind_sweeps = nullptr,
-                            const std::function<int()>* behind_products = nullptr, float radius = -1.f) {
+                            const std::function<int()>* behind_products = nullptr, float radius = -1.f,
+                            const std::function<int()>* defer_redo = nullptr) {
+    // `defer_redo` (not null: the caller asked for no host wait): the solve returns with everything enqueued
+    // and the verdict records unread; onmf_settle_pending reads them at the next entry point and, if they
+    // are not conclusive, runs the solve again the ordinary way and then *defer_redo (what `after` did).
     // `after`: work that consumes H (the step's aggregate products).  When the solve is enqueued as a
     // whole, it is enqueued too BEFORE the host waits for the verdicts, so the GPU does not idle
     // through that round trip; *after_valid tells the caller whether that run stands (it does not if
@@ -555,7 +563,10 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
                 ONMF_TRY(launch_screen_final(c, base, 0, sub_iter - 1, (float)tol, (float)rank_cap, s, next, cw_rows));
             }
             // (the records, and behind them the resolution's own words: NEXT, NRES)
-            HIP_TRY(c, hipMemcpyAsync(c->pinned, base + ScreenLayout::REC,
+            if (!c->rec_pinned)
+                HIP_TRY(c, hipHostMalloc((void**)&c->rec_pinned, (size_t)(4 * SCREEN_MAX_SWEEPS + 4) * sizeof(float),
+                                         hipHostMallocDefault));
+            HIP_TRY(c, hipMemcpyAsync(c->rec_pinned, base + ScreenLayout::REC,
                                       (size_t)(4 * SCREEN_MAX_SWEEPS + 4) * sizeof(float), hipMemcpyDeviceToHost, s));
             if (ahead) {
                 // the host waits for the records only; the follow-up work is already behind them
@@ -564,11 +575,26 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
                 ONMF_TRY(launch_screen_finalize(c, base, sub_iter, buf, H, rb, s));
                 ONMF_TRY((*after)());
                 posted = true;
+                const bool start_intact = H0 == nullptr || (H0 != buf[0] && H0 != buf[1] && H0 != buf[2]);
+                if (defer_redo && start == 0 && dev_rounds == 0 && start_intact && !second_try) {
+                    // not waited for: the next entry point on this context settles it
+                    PendingSolve& p = c->pend;
+                    p.active = true;
+                    p.d = d; p.r = r; p.b = b; p.ldx = ldx; p.sub_iter = sub_iter; p.cw_rows = cw_rows;
+                    p.X = X; p.W = W; p.H0 = H0; p.seed = seed; p.alpha = alpha; p.stopping_diff = stopping_diff;
+                    p.H = H;
+                    for (int q = 0; q < 3; ++q) p.buf[q] = buf[q];
+                    p.probes_new = probes_new;
+                    p.s = s;
+                    p.redo_after = *defer_redo;
+                    if (after_valid) *after_valid = true;
+                    return ONMF_OK;
+                }
                 HIP_TRY(c, hipEventSynchronize(c->ev_rec));
             } else {
                 HIP_TRY(c, hipStreamSynchronize(s));
             }
-            const float* rec = (const float*)c->pinned;
+            const float* rec = (const float*)c->rec_pinned;
             if (dev_rounds > 0) {
                 const int nres = reinterpret_cast<const int*>(rec)[4 * SCREEN_MAX_SWEEPS + 1];
                 if (nres > 0) {
@@ -670,6 +696,7 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
         }
         if (posted && chain_clean) {     // the device put the result in H and the follow-up work stands
             if (after_valid) *after_valid = true;
+            c->sweeps_total += done;
             if (sweeps_done) *sweeps_done = done;
             if (dist_trace)
                 for (int i = done; i < sub_iter; ++i) dist_trace[i] = std::numeric_limits<float>::quiet_NaN();
@@ -747,10 +774,71 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
     }
     if (buf[done % 3] != H)
         HIP_TRY(c, hipMemcpyAsync(H, buf[done % 3], rb * sizeof(float), hipMemcpyDeviceToDevice, s));
+    c->sweeps_total += done;
     if (sweeps_done) *sweeps_done = done;
     if (dist_trace)
         for (int i = done; i < sub_iter; ++i) dist_trace[i] = std::numeric_limits<float>::quiet_NaN();
     return ONMF_OK;
+}
+
+// The verdict records of a solve that was not waited for (ONMF_OPT_DEFER_VERDICT).  Conclusive all the way:
+// the bookkeeping the solve's own end would have done.  Not conclusive (bounds straddle the tolerance in the
+// middle of the solve, or a workgroup gave up waiting): the solve is run again the ordinary way - its
+// inputs are still there, the caller leaves a deferred call's buffers alone until the next call - and then
+// whatever consumed its code.
+int onmf_settle_pending(onmf_ctx* c) {
+    if (!c->pend.active) return ONMF_OK;
+    PendingSolve p = c->pend;
+    c->pend.active = false;
+    c->pend.redo_after = nullptr;
+    HIP_TRY(c, hipEventSynchronize(c->ev_rec));
+    const float* rec = c->rec_pinned;
+    const double tol = (double)p.stopping_diff;
+    double min_margin = 1e300;
+    int done = 0;
+    bool clean = true;
+    for (int i = 0; i < p.sub_iter; ++i) {
+        const int code = (int)rec[4 * i + 2];                 // 0 none, 1 continue, 2 stop, 3 inconclusive
+        if (code == 0) { clean = false; break; }
+        done = i + 1;
+        if (code == 1) {
+            if (i > 0) min_margin = std::min(min_margin, (double)rec[4 * i + 0] / tol);
+            continue;
+        }
+        if (code == 2) break;
+        if (i + 1 == p.sub_iter) continue;                    // the last sweep's test decides nothing
+        clean = false;
+        break;
+    }
+    float* base = (float*)c->screen.p;
+    if (clean) {
+        c->screen_refresh_due = min_margin < 1.5;
+        c->screen_last_undecided = false;
+        if (p.cw_rows > 0 && done >= 1) {
+            ++c->screen_since_refresh;
+            if (p.probes_new || (min_margin < 1.5 && c->screen_since_refresh >= 4)) {
+                ONMF_TRY(launch_screen_refresh(c, base, p.r, p.b, p.buf[done % 3], p.buf[(done + 2) % 3], p.s));
+                c->screen_since_refresh = 0;
+            }
+        }
+        c->sweeps_total += done;
+        return ONMF_OK;
+    }
+    int flag = 0;
+    HIP_TRY(c, hipMemcpy(&flag, base + ScreenLayout::FLAG, sizeof(int), hipMemcpyDeviceToHost));
+    const bool timed_out = flag == SCREEN_FLAG_TIMEOUT;
+    if (timed_out) {
+        ++c->n_sweep_timeouts;
+        c->persistent_backoff = c->persistent_backoff ? std::min(c->persistent_backoff * 2, 1 << 20) : 64;
+        c->persistent_hold = c->persistent_backoff;
+    }
+    c->screen_last_undecided = true;          // the second run does not post its follow-up work ahead
+    c->screen_refresh_due = true;
+    ++c->n_deferred_redone;
+    int sweeps = 0;
+    ONMF_TRY(sparse_code_impl(c, p.d, p.r, p.b, p.X, p.ldx, p.W, p.H0, p.seed, p.alpha, p.sub_iter, p.stopping_diff,
+                              ONMF_CODER_DAMPED, p.H, &sweeps, nullptr, p.s, nullptr, nullptr, timed_out));
+    return p.redo_after ? p.redo_after() : ONMF_OK;
 }
 
 static int aggregate_impl(onmf_ctx* c, int d, int r, int b, const float* X, int ldx, const float* H,
@@ -884,13 +972,19 @@ static int step_impl(onmf_ctx* c, int d, int r, int b, const float* X, int ldx, 
                      const float* dA, const float* dB, const float* gA, const float* gB, const float* gC,
                      const float* H0, uint64_t seed, double w, float alpha, int sub_iter, float stopping_diff,
                      float* H_out, float* A_out, float* B_out, float* C_out, float* W_out, int* sweeps_done,
-                     float* dist_trace, hipStream_t s, hipEvent_t gate) {
+                     float* dist_trace, hipStream_t s, hipEvent_t gate, bool defer = false) {
     float* H = H_out;
     if (!H) {
         // hbuf[] are the sweep ping-pong buffers, so the code gets its own scratch
         ONMF_TRY(onmf_reserve(c, c->dbuf, (size_t)r * b * sizeof(float) * 2, "step code"));
         H = (float*)c->dbuf.p + (size_t)r * b;
     }
+    // what has to be done again, besides the solve, if the verdicts of a step that was not waited for turn
+    // out inconclusive: the aggregate products (by value: it outlives this call)
+    const std::function<int()> redo_products = [=]() {
+        return aggregate_impl(c, d, r, b, X, ldx, H, w, gA, gB, gC, A_out, B_out, C_out, s);
+    };
+    const std::function<int()>* redo = defer ? &redo_products : nullptr;
     const bool aliased = (W_out == W_in) || (A_out == dA) || (B_out == dB);
     // (beside a code solve of a few thousand columns there is little to hide the pass behind, and two
     // latency chains on one chip stretch each other: measured serial vs beside, same box, d=441 r=25
@@ -953,7 +1047,7 @@ static int step_impl(onmf_ctx* c, int d, int r, int b, const float* X, int ldx, 
         if (rc == ONMF_OK)
             rc2 = sparse_code_impl(c, d, r, b, X, ldx, W_in, H0, seed, alpha, sub_iter, stopping_diff,
                                    ONMF_CODER_DAMPED, H, sweeps_done, dist_trace, s, &agg, &agg_done, false, &post_dict,
-                                   &post_whole);
+                                   &post_whole, -1.f, redo);
         if (rc == ONMF_OK && rc2 == ONMF_OK) rc2 = post_whole();       // (a solve that failed early did not get to it)
         if (rc == ONMF_OK && rc2 == ONMF_OK && !agg_done) rc2 = agg();
         hipError_t e1 = hipEventRecord(c->ev_join, c->side);
@@ -990,7 +1084,8 @@ static int step_impl(onmf_ctx* c, int d, int r, int b, const float* X, int ldx, 
             return aggregate_impl(c, d, r, b, X, ldx, H, w, gA, gB, gC, A_out, B_out, C_out, s);
         };
         ONMF_TRY(sparse_code_impl(c, d, r, b, X, ldx, W_in, H0, seed, alpha, sub_iter, stopping_diff,
-                                  ONMF_CODER_DAMPED, H, sweeps_done, dist_trace, s, &agg, &agg_done));
+                                  ONMF_CODER_DAMPED, H, sweeps_done, dist_trace, s, &agg, &agg_done, false, nullptr,
+                                  nullptr, -1.f, redo));
         if (!agg_done) ONMF_TRY(agg());
         return dict_check(c, d, r, W_in, dA, dB, W_out, s);
     }
@@ -1015,9 +1110,16 @@ int onmf_step(onmf_ctx* c, int d, int r, int b, const float* X, int ldx, const f
     if (!W_in || !A_in || !B_in || !A_out || !B_out || !W_out)
         return onmf_fail(c, ONMF_ERR_ARG, "step: null state pointer");
     ONMF_ENTER(c);
+    const bool defer = c->defer_verdict && !sweeps_done && !dist_trace;
     return step_impl(c, d, r, b, X, ldx, W_in, A_in, B_in, A_in, B_in, C_in, H0, seed, w, alpha, sub_iter,
                      stopping_diff, H_out, A_out, B_out, C_out, W_out, sweeps_done, dist_trace,
-                     (hipStream_t)stream, nullptr);
+                     (hipStream_t)stream, nullptr, defer);
+}
+
+int onmf_settle(onmf_ctx* c) {
+    if (!c) return ONMF_ERR_ARG;
+    ONMF_ENTER(c);           // (settles)
+    return ONMF_OK;
 }
 
 size_t onmf_partial_floats(int d, int r) { return (((size_t)r * r + 3) & ~(size_t)3) + (size_t)r * d; }

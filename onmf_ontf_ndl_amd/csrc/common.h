@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -20,6 +21,22 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
+};
+
+// A step whose stopping-test verdicts the host has not looked at yet (ONMF_OPT_DEFER_VERDICT): everything
+// was enqueued on the assumption that the device's verdicts are conclusive; the next entry point on the
+// context reads the records and, where they are not, runs the solve and what consumed its code again.
+struct PendingSolve {
+    bool active = false;
+    int d = 0, r = 0, b = 0, ldx = 0, sub_iter = 0, cw_rows = 0;
+    const float *X = nullptr, *W = nullptr, *H0 = nullptr;
+    uint64_t seed = 0;
+    float alpha = 0.f, stopping_diff = 0.f;
+    float* H = nullptr;
+    float* buf[3] = {nullptr, nullptr, nullptr};
+    bool probes_new = false;
+    hipStream_t s = nullptr;
+    std::function<int()> redo_after;        // what consumed the code (the step's aggregate products), by value
 };
 
 struct onmf_ctx {
@@ -84,6 +101,12 @@ struct onmf_ctx {
     DevBuf gram64, cm64, lars_ws, lars_meta, lars_overflow;
     bool lars_hint_ok = false;            // a LARS call of this context has published its slot count
     int lars_slots = 0;                   // ONMF_OPT_LARS_SLOTS
+    // verdicts looked at by the next call instead of this one
+    int defer_verdict = 0;                // ONMF_OPT_DEFER_VERDICT
+    PendingSolve pend;
+    float* rec_pinned = nullptr;          // host staging of the verdict records (its own: a pending solve keeps it)
+    long long sweeps_total = 0;           // sweeps of all settled solves
+    long long n_deferred_redone = 0;      // deferred solves that had to be run again
     // NumPy's MT19937 stream on the device (mt19937.hip): jump table, head words, chunk blocks, final block
     DevBuf mt;
     int mt_rows = -1;                     // rows of the jump table held (-1: buffers not set up)
@@ -106,11 +129,16 @@ struct DeviceGuard {
     DeviceGuard(const DeviceGuard&) = delete;
     DeviceGuard& operator=(const DeviceGuard&) = delete;
 };
+int onmf_settle_pending(onmf_ctx* c);
 #define ONMF_ENTER(ctx)                                                                          \
     DeviceGuard _device_guard((ctx)->device);                                                    \
     if (_device_guard.err != hipSuccess)                                                         \
         return onmf_fail((ctx), ONMF_ERR_HIP, "selecting device %d failed: %s", (ctx)->device,   \
-                         hipGetErrorString(_device_guard.err))
+                         hipGetErrorString(_device_guard.err));                                  \
+    if ((ctx)->pend.active) {                                                                    \
+        const int _settle_rc = onmf_settle_pending(ctx);                                         \
+        if (_settle_rc != ONMF_OK) return _settle_rc;                                            \
+    }
 
 int onmf_fail(onmf_ctx* c, int code, const char* fmt, ...);
 int onmf_reserve(onmf_ctx* c, DevBuf& b, size_t bytes, const char* what);

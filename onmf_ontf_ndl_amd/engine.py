@@ -98,7 +98,8 @@ class Engine:
         out = {}
         for name, key in (("sweep_timeouts", _lib.CNT_SWEEP_TIMEOUTS), ("dict_timeouts", _lib.CNT_DICT_TIMEOUTS),
                           ("fallback_solves", _lib.CNT_FALLBACK_SOLVES),
-                          ("device_resolves", _lib.CNT_DEVICE_RESOLVES), ("lars_recoded", _lib.CNT_LARS_RECODED), ("lars_slots_used", _lib.CNT_LARS_SLOTS_USED)):
+                          ("device_resolves", _lib.CNT_DEVICE_RESOLVES), ("lars_recoded", _lib.CNT_LARS_RECODED), ("lars_slots_used", _lib.CNT_LARS_SLOTS_USED), ("sweeps_total", _lib.CNT_SWEEPS_TOTAL),
+                          ("deferred_redone", _lib.CNT_DEFERRED_REDONE)):
             v = C.c_longlong(0)
             _lib.check(self.lib.onmf_get_counter(self.ctx, key, C.byref(v)), self.ctx, "onmf_get_counter")
             out[name] = int(v.value)
@@ -205,11 +206,18 @@ class Engine:
         _lib.check(rc, self.ctx, "onmf_update_dict_static")
         return W1
 
+    def settle(self):
+        """Have the library look at the verdicts of a step that was not waited for (``step(..., defer=True)``)."""
+        _lib.check(self.lib.onmf_settle(self.ctx), self.ctx, "onmf_settle")
+
     def step(self, X, A, B, Cagg, W, w, alpha=0.0, H0=None, seed=None, sub_iter=10,
-             stopping_diff=0.01, want_code=True, out=None):
+             stopping_diff=0.01, want_code=True, out=None, defer=False):
         """One minibatch step (onmf.py:119-167). Returns H1, A1, B1, C1, W1, sweeps, dist.
         ``out`` = (A1, B1, W1): tensors to write the new state into (e.g. views of a packed buffer);
-        they must not be the input tensors if the step is to keep its three-stream schedule."""
+        they must not be the input tensors if the step is to keep its three-stream schedule.
+        ``defer``: do not wait for the stopping test's verdicts (ONMF_OPT_DEFER_VERDICT must be set): sweeps and
+        dist come back as None; inputs must stay untouched and H1, A1, B1, C1 are only to be handed to the next
+        call on this engine (or read after ``settle()``)."""
         d, b = X.shape
         r = W.shape[1]
         if out is None:
@@ -225,6 +233,15 @@ class Engine:
         trace = (C.c_float * max(1, int(sub_iter)))()
         if seed is None:
             seed = self.next_seed()
+        if defer:
+            # the tensors of this call must outlive it: the library may run the solve again at the next call
+            self._deferred_keep = (X, A, B, Cagg, W, H0, H, A1, B1, C1, W1)
+            rc = self.lib.onmf_step(self.ctx, d, r, b, _ptr(X), X.stride(0), _ptr(W), _ptr(A), _ptr(B),
+                                    _ptr(Cagg), _ptr(H0), C.c_uint64(seed), float(w), float(alpha),
+                                    int(sub_iter), float(stopping_diff), _ptr(H), _ptr(A1), _ptr(B1),
+                                    _ptr(C1), _ptr(W1), None, None, self.stream())
+            _lib.check(rc, self.ctx, "onmf_step")
+            return H, A1, B1, C1, W1, None, None
         rc = self.lib.onmf_step(self.ctx, d, r, b, _ptr(X), X.stride(0), _ptr(W), _ptr(A), _ptr(B),
                                 _ptr(Cagg), _ptr(H0), C.c_uint64(seed), float(w), float(alpha),
                                 int(sub_iter), float(stopping_diff), _ptr(H), _ptr(A1), _ptr(B1),

@@ -287,3 +287,48 @@ def test_workgroup_geometries_agree_bit_for_bit(eng, d, r, b):
     finally:
         eng.set_option(3, 0)
     assert sa == sb and torch.equal(Ha, Hb)
+
+
+DEFER = 11
+
+
+@pytest.mark.parametrize("d,r,b,tol_kind", [(100, 16, 1000, "plain"), (200, 64, 3000, "plain"), (200, 64, 3000, "hug"),
+                                            (96, 256, 2048, "hug"), (128, 100, 4096, "plain")])
+def test_steps_that_do_not_wait_for_their_verdicts(eng, d, r, b, tol_kind):
+    """ONMF_OPT_DEFER_VERDICT: a chain of onmf_step calls that return no host scalars and never wait for the
+    GPU must leave the same state, bit for bit, and run the same number of sweeps as the chain that reads
+    every verdict - also when the tolerance hugs an actual dist value, so that verdicts come out
+    inconclusive and the library has to run those steps' solves again at the next call."""
+    import torch
+    g = torch.Generator(device=eng.device).manual_seed(7 * d + r)
+    Xs = [torch.rand(d, b, device=eng.device, generator=g) for _ in range(6)]
+    W0 = torch.rand(d, r, device=eng.device, generator=g)
+    W0 = W0 / torch.clamp(torch.linalg.norm(W0, dim=0), min=1.0)
+    tol = 0.01
+    if tol_kind == "hug":
+        eng.set_option(EXACT, 1)
+        _, _, de = eng.sparse_code(Xs[1], W0, H0=None, seed=1001, stopping_diff=0.0)
+        eng.set_option(EXACT, 0)
+        tol = float(de[5] * 0.995)
+    results = []
+    for defer in (False, True):
+        eng.set_option(DEFER, 1 if defer else 0)
+        A, B, W = eng.zeros(r, r), eng.zeros(r, d), W0.clone()
+        c0 = eng.counters()
+        sweeps = []
+        try:
+            for t, X in enumerate(Xs):
+                H, A, B, _, W, s, _ = eng.step(X, A, B, None, W, 1.0 / (t + 1), seed=1000 + t, stopping_diff=tol,
+                                               defer=defer)
+                sweeps.append(s)
+            eng.settle()
+        finally:
+            eng.set_option(DEFER, 0)
+        torch.cuda.synchronize()
+        c1 = eng.counters()
+        results.append((H.clone(), A.clone(), B.clone(), W.clone(), c1["sweeps_total"] - c0["sweeps_total"],
+                        c1["deferred_redone"] - c0["deferred_redone"], sweeps))
+    (H1, A1, B1, W1, n1, _, sw1), (H2, A2, B2, W2, n2, redone, sw2) = results
+    print("d=%d r=%d b=%d tol=%.4g: sweeps %s, deferred chain: %d solves run again" % (d, r, b, tol, sw1, redone))
+    assert all(s is None for s in sw2) and n1 == sum(sw1) == n2
+    assert torch.equal(W1, W2) and torch.equal(A1, A2) and torch.equal(B1, B2) and torch.equal(H1, H2)
