@@ -234,6 +234,17 @@ int onmf_sparse_code_each(onmf_ctx* ctx, int d, int r, int b, const float* X, in
 int onmf_sparse_code_lars(onmf_ctx* ctx, int d, int r, int b, const float* X, int ldx, const float* W,
                           double alpha, int max_iter, float* H, int32_t* info, void* stream);
 
+/*
+ * Online_NTF.step(X, A, B, W, t), src/ontf.py:117-154: the coder above, the aggregate recursion
+ * (A_out = (1-w) A_in + w H H^T, B_out = (1-w) B_in + w H X^T with H as r x b; src/ontf.py:147-148 in the
+ * reference's b x r convention) and the dictionary pass on the aggregates from BEFORE the step
+ * (src/ontf.py:151), which runs on a second stream beside the coder when no output is one of the inputs.
+ * w = t^(-beta).  H_out (r x b) may be NULL.  Asynchronous on `stream`.
+ */
+int onmf_ntf_step(onmf_ctx* ctx, int d, int r, int b, const float* X, int ldx, const float* W_in,
+                  const float* A_in, const float* B_in, double w, double alpha, int max_iter, float* H_out,
+                  float* A_out, float* B_out, float* W_out, int32_t* info, void* stream);
+
 /* R = W H (d x b, leading dimension ldr): np.dot(self.W, code), image_reconstruction.py:352, :385. */
 int onmf_patch_product(onmf_ctx* ctx, int d, int r, int b, const float* W, const float* H, float* R,
                        int ldr, void* stream);

@@ -77,6 +77,8 @@ SIGNATURES = {
                                         C.c_float, C.c_int, C.c_float, C.c_int, _f, C.c_void_p, C.c_void_p]),
     "onmf_sparse_code_lars": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, _f, C.c_int, _f, C.c_double, C.c_int, _f,
                                         C.c_void_p, C.c_void_p]),
+    "onmf_ntf_step": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, _f, C.c_int, _f, _f, _f, C.c_double, C.c_double, C.c_int,
+                                _f, _f, _f, _f, C.c_void_p, C.c_void_p]),
     "onmf_patch_product": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, _f, _f, _f, C.c_int, C.c_void_p]),
     "onmf_extract_patches": (C.c_int, [_ctx, _f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                        C.c_int, C.c_int, C.c_int, _f, C.c_int, C.c_void_p]),

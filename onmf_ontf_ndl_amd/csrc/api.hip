@@ -1241,6 +1241,55 @@ int onmf_sparse_code_lars(onmf_ctx* c, int d, int r, int b, const float* X, int 
     return launch_lars_pos(c, r, b, Gd, Cd, b, alpha, (double)d, max_iter, H, b, info, s);
 }
 
+int onmf_ntf_step(onmf_ctx* c, int d, int r, int b, const float* X, int ldx, const float* W_in, const float* A_in,
+                  const float* B_in, double w, double alpha, int max_iter, float* H_out, float* A_out, float* B_out,
+                  float* W_out, int32_t* info, void* stream) {
+    if (!c) return ONMF_ERR_ARG;
+    if (d <= 0 || r <= 0 || b <= 0 || !X || !W_in || !A_in || !B_in || !A_out || !B_out || !W_out || ldx < b ||
+        max_iter < 0 || !(alpha >= 0.0) || r > 256)
+        return onmf_fail(c, ONMF_ERR_ARG, "ntf_step: bad arguments (d=%d r=%d b=%d ldx=%d alpha=%g)", d, r, b, ldx, alpha);
+    hipStream_t s = (hipStream_t)stream;
+    ONMF_ENTER(c);
+    float* H = H_out;
+    if (!H) {
+        ONMF_TRY(onmf_reserve(c, c->dbuf, (size_t)r * b * sizeof(float) * 2, "step code"));
+        H = (float*)c->dbuf.p + (size_t)r * b;
+    }
+    ONMF_TRY(onmf_reserve(c, c->gram64, (size_t)r * r * sizeof(double), "Gm (double)"));
+    ONMF_TRY(onmf_reserve(c, c->cm64, (size_t)r * b * sizeof(double), "Cm (double)"));
+    double* Gd = (double*)c->gram64.p;
+    double* Cd = (double*)c->cm64.p;
+    // the dictionary pass reads the aggregates from before the step (src/ontf.py:151) and nothing of the code:
+    // it runs on the side stream beside the coder when its output is not one of the step's inputs
+    const bool beside = c->overlap_dict && W_out != W_in && A_out != A_in && B_out != B_in;
+    if (beside) {
+        if (!c->side) {
+            HIP_TRY(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+            HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, EV_ORDER_ONLY));
+            HIP_TRY(c, hipEventCreateWithFlags(&c->ev_join, EV_ORDER_ONLY));
+        }
+        HIP_TRY(c, hipEventRecord(c->ev_fork, s));
+        HIP_TRY(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
+    }
+    int rc_dict = beside ? launch_dict_pass(c, d, r, W_in, A_in, B_in, W_out, c->side, 0) : ONMF_OK;
+    int rc = launch_prod_f64(c, r, r, d, W_in, r, W_in, r, Gd, r, s);
+    if (rc == ONMF_OK) rc = launch_prod_f64(c, r, b, d, W_in, r, X, ldx, Cd, b, s);
+    if (rc == ONMF_OK) rc = launch_lars_pos(c, r, b, Gd, Cd, b, alpha, (double)d, max_iter, H, b, info, s);
+    if (rc == ONMF_OK && !beside) rc = launch_dict_pass(c, d, r, W_in, A_in, B_in, W_out, s, 0);
+    if (rc == ONMF_OK) rc = aggregate_impl(c, d, r, b, X, ldx, H, w, A_in, B_in, nullptr, A_out, B_out, nullptr, s);
+    if (beside) {       // always rejoin, also on an error path
+        hipError_t e1 = hipEventRecord(c->ev_join, c->side);
+        hipError_t e2 = hipStreamWaitEvent(s, c->ev_join, 0);
+        if (rc == ONMF_OK && rc_dict == ONMF_OK) {
+            HIP_TRY(c, e1);
+            HIP_TRY(c, e2);
+        }
+    }
+    ONMF_TRY(rc_dict);
+    ONMF_TRY(rc);
+    return dict_check(c, d, r, W_in, A_in, B_in, W_out, s);
+}
+
 int onmf_patch_product(onmf_ctx* c, int d, int r, int b, const float* W, const float* H, float* R, int ldr,
                        void* stream) {
     if (!c) return ONMF_ERR_ARG;

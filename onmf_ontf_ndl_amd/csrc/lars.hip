@@ -37,7 +37,7 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 // Out[m][n] = sum_k A[k*lda + m] * B[k*ldb + n]   (float operands, double accumulation and result)
 // 64 x 64 output tile per workgroup of four waves; wave w: rows 16w .. 16w+15, four 16-column blocks.
 // ---------------------------------------------------------------------------------------------
-constexpr int PT = 64, PK = 16, PPITCH = 80;
+constexpr int PT = 64, PK = 64, PPITCH = 80;
 
 __global__ __launch_bounds__(256) void prod_f64_kernel(int M, int N, int K, const float* __restrict__ A, int lda,
                                                        const float* __restrict__ B, int ldb,
@@ -48,25 +48,32 @@ __global__ __launch_bounds__(256) void prod_f64_kernel(int M, int N, int K, cons
     f64x4 acc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] = f64x4{0.0, 0.0, 0.0, 0.0};
+    // a tile is PK contraction steps x 64 columns per operand: thread t fetches rows (t >> 4) + 16 j, four
+    // consecutive columns each - the next tile's 2 x 16 loads are in flight while this one is multiplied
     const int lk = tid >> 4, lx = (tid & 15) * 4;
-    float ra[4], rb[4];
+    float ra[PK / 16][4], rb[PK / 16][4];
     auto fetch = [&](int k0) {
-        const int k = k0 + lk;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m0 + lx + i, n = n0 + lx + i;
-            ra[i] = (k < K && m < M) ? A[(size_t)k * lda + m] : 0.f;
-            rb[i] = (k < K && n < N) ? B[(size_t)k * ldb + n] : 0.f;
+        for (int j = 0; j < PK / 16; ++j) {
+            const int k = k0 + lk + 16 * j;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = m0 + lx + i, n = n0 + lx + i;
+                ra[j][i] = (k < K && m < M) ? A[(size_t)k * lda + m] : 0.f;
+                rb[j][i] = (k < K && n < N) ? B[(size_t)k * ldb + n] : 0.f;
+            }
         }
     };
     fetch(0);
     for (int k0 = 0; k0 < K; k0 += PK) {
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            sa[lk * PPITCH + lx + i] = ra[i];
-            sb[lk * PPITCH + lx + i] = rb[i];
-        }
+        for (int j = 0; j < PK / 16; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                sa[(lk + 16 * j) * PPITCH + lx + i] = ra[j][i];
+                sb[(lk + 16 * j) * PPITCH + lx + i] = rb[j][i];
+            }
         __syncthreads();
         if (k0 + PK < K) fetch(k0 + PK);
 #pragma unroll
@@ -206,6 +213,33 @@ struct Inv {
     __device__ __forceinline__ bool mine(int i, int j) const { return PACKED ? j <= i : true; }
 };
 
+// The used slots GN at a time: f(q, pos, n) with pos[0 .. n-1] the slots' positions in word q of the mask
+// (pos[n .. GN-1] repeat pos[0]: callers give them weight zero).  A pass over the inverse, or over rows of G,
+// is a chain of dependent memory round trips when it takes its rows one by one; in groups, the rows of a
+// group travel together.
+template <int GN, int SQ, class F>
+__device__ __forceinline__ void for_used(const unsigned long long (&used)[SQ], F&& f) {
+#pragma unroll
+    for (int qi = 0; qi < SQ; ++qi) {
+        unsigned long long m = used[qi];
+        while (m) {
+            int pos[GN];
+            int n = 0;
+#pragma unroll
+            for (int u = 0; u < GN; ++u) {
+                if (m) {
+                    pos[u] = __builtin_ctzll(m);
+                    m &= m - 1;
+                    n = u + 1;
+                } else {
+                    pos[u] = pos[0];
+                }
+            }
+            f(qi, pos, n);
+        }
+    }
+}
+
 // Q: atoms per lane (r <= 64 Q); SQ: slots per lane (n_cap <= 64 SQ)
 template <int Q, int SQ, bool P_LDS>
 __global__ __launch_bounds__(256) void lars_pos_kernel(const LarsArgs a) {
@@ -262,18 +296,18 @@ __global__ __launch_bounds__(256) void lars_pos_kernel(const LarsArgs a) {
         auto column_sums = [&]() {
 #pragma unroll
             for (int q = 0; q < SQ; ++q) w[q] = 0.0;
+            for_used<4>(used, [&](int qi, const int (&pos)[4], int n) {
+                double pv[4][SQ];
 #pragma unroll
-            for (int qi = 0; qi < SQ; ++qi) {
-                unsigned long long m = used[qi];
-                while (m) {
-                    const int ii = __builtin_ctzll(m);
-                    m &= m - 1;
-                    const int i = 64 * qi + ii;
+                for (int u = 0; u < 4; ++u)
 #pragma unroll
                     for (int q = 0; q < SQ; ++q)
-                        if (slot_used(q)) w[q] += P.at(i, lane + 64 * q);
-                }
-            }
+                        pv[u][q] = (u < n && slot_used(q)) ? P.at(64 * qi + pos[u], lane + 64 * q) : 0.0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int q = 0; q < SQ; ++q) w[q] += pv[u][q];
+            });
         };
 
         for (;;) {
@@ -320,19 +354,20 @@ __global__ __launch_bounds__(256) void lars_pos_kernel(const LarsArgs a) {
                 }
                 const double gvv = G[(size_t)v * r + v];
                 // u = inverse . g
+                for_used<4>(used, [&](int qi, const int (&pos)[4], int n) {
+                    double pv[4][SQ], gi[4];
 #pragma unroll
-                for (int qi = 0; qi < SQ; ++qi) {
-                    unsigned long long m = used[qi];
-                    while (m) {
-                        const int ii = __builtin_ctzll(m);
-                        m &= m - 1;
-                        const int i = 64 * qi + ii;
-                        const double gi = lane_value(g[qi], ii);
+                    for (int u4 = 0; u4 < 4; ++u4) {
+                        gi[u4] = u4 < n ? lane_value(g[qi], pos[u4]) : 0.0;
 #pragma unroll
                         for (int q = 0; q < SQ; ++q)
-                            if (slot_used(q)) u[q] += P.at(i, lane + 64 * q) * gi;
+                            pv[u4][q] = (u4 < n && slot_used(q)) ? P.at(64 * qi + pos[u4], lane + 64 * q) : 0.0;
                     }
-                }
+#pragma unroll
+                    for (int u4 = 0; u4 < 4; ++u4)
+#pragma unroll
+                        for (int q = 0; q < SQ; ++q) u[q] += pv[u4][q] * gi[u4];
+                });
                 double gu = 0.0;
 #pragma unroll
                 for (int q = 0; q < SQ; ++q) gu += g[q] * u[q];
@@ -356,21 +391,25 @@ __global__ __launch_bounds__(256) void lars_pos_kernel(const LarsArgs a) {
                 }
                 peak_slots = max(peak_slots, knew + 1);
                 // inverse += u u^T / s over the used slots; the new slot's row and column
+                for_used<4>(used, [&](int qi, const int (&pos)[4], int n) {
+                    double pv[4][SQ], ui[4];
 #pragma unroll
-                for (int qi = 0; qi < SQ; ++qi) {
-                    unsigned long long m = used[qi];
-                    while (m) {
-                        const int ii = __builtin_ctzll(m);
-                        m &= m - 1;
-                        const int i = 64 * qi + ii;
-                        const double ui = lane_value(u[qi], ii);
+                    for (int u4 = 0; u4 < 4; ++u4) {
+                        ui[u4] = u4 < n ? lane_value(u[qi], pos[u4]) : 0.0;
 #pragma unroll
                         for (int q = 0; q < SQ; ++q) {
-                            const int k = lane + 64 * q;
-                            if (slot_used(q) && P.mine(i, k)) P.at(i, k) += (ui * u[q]) * sinv;
+                            const int i = 64 * qi + pos[u4], k = lane + 64 * q;
+                            pv[u4][q] = (u4 < n && slot_used(q) && P.mine(i, k)) ? P.at(i, k) : 0.0;
                         }
                     }
-                }
+#pragma unroll
+                    for (int u4 = 0; u4 < 4; ++u4)
+#pragma unroll
+                        for (int q = 0; q < SQ; ++q) {
+                            const int i = 64 * qi + pos[u4], k = lane + 64 * q;
+                            if (u4 < n && slot_used(q) && P.mine(i, k)) P.at(i, k) = pv[u4][q] + (ui[u4] * u[q]) * sinv;
+                        }
+                });
 #pragma unroll
                 for (int q = 0; q < SQ; ++q) {
                     const int k = lane + 64 * q;
@@ -415,21 +454,23 @@ __global__ __launch_bounds__(256) void lars_pos_kernel(const LarsArgs a) {
             double corr[Q];
 #pragma unroll
             for (int q = 0; q < Q; ++q) corr[q] = 0.0;
+            for_used<8>(used, [&](int qi, const int (&pos)[8], int n) {
+                double gv[8][Q], li[8];
 #pragma unroll
-            for (int qi = 0; qi < SQ; ++qi) {
-                unsigned long long m = used[qi];
-                while (m) {
-                    const int ii = __builtin_ctzll(m);
-                    m &= m - 1;
-                    const int av = __builtin_amdgcn_readlane(act[qi], ii);
-                    const double li = lane_value(ls[qi], ii);
+                for (int u8 = 0; u8 < 8; ++u8) {
+                    const int av = __builtin_amdgcn_readlane(act[qi], pos[u8]);
+                    li[u8] = u8 < n ? lane_value(ls[qi], pos[u8]) : 0.0;
 #pragma unroll
                     for (int q = 0; q < Q; ++q) {
                         const int j = lane + 64 * q;
-                        if (j < r) corr[q] += G[(size_t)av * r + j] * li;
+                        gv[u8][q] = (u8 < n && j < r) ? G[(size_t)av * r + j] : 0.0;
                     }
                 }
-            }
+#pragma unroll
+                for (int u8 = 0; u8 < 8; ++u8)
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) corr[q] += gv[u8][q] * li[u8];
+            });
             // step to the next atom that ties with the active ones, or to zero correlation (:806-808)
             double t1 = DBL_MAX;
 #pragma unroll
@@ -493,21 +534,26 @@ __global__ __launch_bounds__(256) void lars_pos_kernel(const LarsArgs a) {
                         if ((k >> 6) == q) used[q] &= ~(1ull << (k & 63));
                     pass_fence();
                     // inverse of the remaining atoms: inverse -= p p^T / p_kk
+                    for_used<4>(used, [&](int qi, const int (&pos)[4], int n) {
+                        double pv[4][SQ], pi[4];
 #pragma unroll
-                    for (int qi = 0; qi < SQ; ++qi) {
-                        unsigned long long m = used[qi];
-                        while (m) {
-                            const int ii = __builtin_ctzll(m);
-                            m &= m - 1;
-                            const int i = 64 * qi + ii;
-                            const double pi = lane_value(p[qi], ii);
+                        for (int u4 = 0; u4 < 4; ++u4) {
+                            pi[u4] = u4 < n ? lane_value(p[qi], pos[u4]) : 0.0;
 #pragma unroll
                             for (int q = 0; q < SQ; ++q) {
-                                const int kk = lane + 64 * q;
-                                if (slot_used(q) && P.mine(i, kk)) P.at(i, kk) -= (pi * p[q]) * pinv;
+                                const int i = 64 * qi + pos[u4], kk = lane + 64 * q;
+                                pv[u4][q] = (u4 < n && slot_used(q) && P.mine(i, kk)) ? P.at(i, kk) : 0.0;
                             }
                         }
-                    }
+#pragma unroll
+                        for (int u4 = 0; u4 < 4; ++u4)
+#pragma unroll
+                            for (int q = 0; q < SQ; ++q) {
+                                const int i = 64 * qi + pos[u4], kk = lane + 64 * q;
+                                if (u4 < n && slot_used(q) && P.mine(i, kk))
+                                    P.at(i, kk) = pv[u4][q] - (pi[u4] * p[q]) * pinv;
+                            }
+                    });
                     // its correlation, recomputed from the data (:889)
                     double dot = 0.0;
 #pragma unroll

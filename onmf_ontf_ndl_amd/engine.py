@@ -358,6 +358,23 @@ class Engine:
         _lib.check(rc, self.ctx, "onmf_sparse_code_lars")
         return (H, info) if want_info else H
 
+    def ntf_step(self, X, A, B, W, w, alpha=2.0, max_iter=1000, want_code=True):
+        """Online_NTF.step (src/ontf.py:117-154) with the LARS coder: H (r x b), A1, B1, W1; the dictionary pass
+        runs beside the coder on the library's second stream."""
+        d, b = X.shape
+        r = W.shape[1]
+        if W.shape[0] != d or tuple(A.shape) != (r, r) or tuple(B.shape) != (r, d):
+            raise ValueError("ntf_step: shapes of X (d,b), W (d,r), A (r,r), B (r,d) do not agree")
+        H = self.empty(r, b) if want_code else None
+        A1, B1, W1 = self.empty(r, r), self.empty(r, d), self.empty(d, r)
+        rc = self.lib.onmf_ntf_step(self.ctx, d, r, b, _ptr(X), X.stride(0), _ptr(W), _ptr(A), _ptr(B), float(w),
+                                    float(alpha), int(max_iter), _ptr(H), _ptr(A1), _ptr(B1), _ptr(W1), None,
+                                    self.stream())
+        _lib.check(rc, self.ctx, "onmf_ntf_step")
+        if d > 1024:
+            self._warn_on_timeouts()
+        return H, A1, B1, W1
+
     def patch_product(self, W, H):
         """W @ H (image_reconstruction.py:352, :385)."""
         d, r = W.shape

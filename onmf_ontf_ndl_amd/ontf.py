@@ -115,8 +115,13 @@ class Online_NTF():
         return _out(eng.update_dict(eng.dev(W), eng.dev(A), eng.dev(B)), _is_torch(W))
 
     def _step_dev(self, eng, Xd, Ad, Bd, Wd, t):
-        H = self._code_dev(eng, Xd, Wd)
         w = _weight(t, self.beta)
+        if self.coder == "lars" and Wd.shape[1] <= 256:
+            a = 2 if self.alpha is None else self.alpha      # src/ontf.py:79-84
+            H, A1, B1, W1 = eng.ntf_step(Xd, Ad, Bd, Wd, w, alpha=a, max_iter=self.lars_max_iter)
+            self.history = np.float64(t) + 1
+            return H, A1, B1, W1
+        H = self._code_dev(eng, Xd, Wd)
         A1, B1, _ = eng.aggregate(Xd, H, w, Ad, Bd)          # src/ontf.py:147-148
         W1 = eng.update_dict(Wd, Ad, Bd)                      # old aggregates, src/ontf.py:151
         self.history = np.float64(t) + 1
