@@ -292,23 +292,16 @@ __global__ __launch_bounds__(256) void lars_pos_kernel(const LarsArgs a) {
         double alpha = 0.0, prev_alpha = 0.0;
 
         auto slot_used = [&](int q) -> bool { return (used[q] >> lane) & 1ull; };
-        // w = column sums of the inverse over the used slots
-        auto column_sums = [&]() {
+        // Loads of the passes below are unconditional, from an address that is always inside the wave's own
+        // storage (the lane's slot, or the last slot for lanes beyond them), and what an unused lane read is
+        // replaced by zero afterwards: a select per value instead of a masked branch per load.
+        int kc[SQ], jc[Q];
 #pragma unroll
-            for (int q = 0; q < SQ; ++q) w[q] = 0.0;
-            for_used<4>(used, [&](int qi, const int (&pos)[4], int n) {
-                double pv[4][SQ];
+        for (int q = 0; q < SQ; ++q) kc[q] = min(lane + 64 * q, n_cap - 1);
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-#pragma unroll
-                    for (int q = 0; q < SQ; ++q)
-                        pv[u][q] = (u < n && slot_used(q)) ? P.at(64 * qi + pos[u], lane + 64 * q) : 0.0;
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-#pragma unroll
-                    for (int q = 0; q < SQ; ++q) w[q] += pv[u][q];
-            });
-        };
+        for (int q = 0; q < Q; ++q) jc[q] = min(lane + 64 * q, r - 1);
+        // w = inverse . 1 (the column sums of the inverse) is carried along: an atom that enters or leaves
+        // changes it by a multiple of the vector that changes the inverse
 
         for (;;) {
             // largest correlation among the inactive atoms (_least_angle.py:634-647)
@@ -360,9 +353,12 @@ __global__ __launch_bounds__(256) void lars_pos_kernel(const LarsArgs a) {
                     for (int u4 = 0; u4 < 4; ++u4) {
                         gi[u4] = u4 < n ? lane_value(g[qi], pos[u4]) : 0.0;
 #pragma unroll
-                        for (int q = 0; q < SQ; ++q)
-                            pv[u4][q] = (u4 < n && slot_used(q)) ? P.at(64 * qi + pos[u4], lane + 64 * q) : 0.0;
+                        for (int q = 0; q < SQ; ++q) pv[u4][q] = P.at(64 * qi + pos[u4], kc[q]);
                     }
+#pragma unroll
+                    for (int u4 = 0; u4 < 4; ++u4)
+#pragma unroll
+                        for (int q = 0; q < SQ; ++q) pv[u4][q] = slot_used(q) ? pv[u4][q] : 0.0;
 #pragma unroll
                     for (int u4 = 0; u4 < 4; ++u4)
 #pragma unroll
@@ -397,10 +393,7 @@ __global__ __launch_bounds__(256) void lars_pos_kernel(const LarsArgs a) {
                     for (int u4 = 0; u4 < 4; ++u4) {
                         ui[u4] = u4 < n ? lane_value(u[qi], pos[u4]) : 0.0;
 #pragma unroll
-                        for (int q = 0; q < SQ; ++q) {
-                            const int i = 64 * qi + pos[u4], k = lane + 64 * q;
-                            pv[u4][q] = (u4 < n && slot_used(q) && P.mine(i, k)) ? P.at(i, k) : 0.0;
-                        }
+                        for (int q = 0; q < SQ; ++q) pv[u4][q] = P.at(64 * qi + pos[u4], kc[q]);
                     }
 #pragma unroll
                     for (int u4 = 0; u4 < 4; ++u4)
@@ -430,7 +423,17 @@ __global__ __launch_bounds__(256) void lars_pos_kernel(const LarsArgs a) {
                     if ((knew >> 6) == q) used[q] |= 1ull << (knew & 63);
                 ++n_active;
                 pass_fence();
-                column_sums();
+                // inverse . 1: old slots gain u (sum(u) - 1) / s, the new slot holds (1 - sum(u)) / s
+                double su = 0.0;
+#pragma unroll
+                for (int q = 0; q < SQ; ++q) su += u[q];
+                su = uni(wave_sum(su));
+                const double f = (su - 1.0) * sinv;
+#pragma unroll
+                for (int q = 0; q < SQ; ++q) {
+                    w[q] += u[q] * f;
+                    if (lane + 64 * q == knew) w[q] = (1.0 - su) * sinv;
+                }
             }
             if (n_iter > 0 && prev_alpha < alpha) {                  // :748-761
                 end = 3;
@@ -450,7 +453,7 @@ __global__ __launch_bounds__(256) void lars_pos_kernel(const LarsArgs a) {
                 if (slot_used(q)) lsv[lane + 64 * q] = ls[q];
             }
             pass_fence();
-            // correlation of every atom with the direction (:800)
+            // correlation of every atom with the direction (:800); lanes beyond r compute a value nobody reads
             double corr[Q];
 #pragma unroll
             for (int q = 0; q < Q; ++q) corr[q] = 0.0;
@@ -461,10 +464,7 @@ __global__ __launch_bounds__(256) void lars_pos_kernel(const LarsArgs a) {
                     const int av = __builtin_amdgcn_readlane(act[qi], pos[u8]);
                     li[u8] = u8 < n ? lane_value(ls[qi], pos[u8]) : 0.0;
 #pragma unroll
-                    for (int q = 0; q < Q; ++q) {
-                        const int j = lane + 64 * q;
-                        gv[u8][q] = (u8 < n && j < r) ? G[(size_t)av * r + j] : 0.0;
-                    }
+                    for (int q = 0; q < Q; ++q) gv[u8][q] = G[(size_t)av * r + jc[q]];
                 }
 #pragma unroll
                 for (int u8 = 0; u8 < 8; ++u8)
@@ -523,7 +523,14 @@ __global__ __launch_bounds__(256) void lars_pos_kernel(const LarsArgs a) {
                         if ((v >> 6) == q) k = __builtin_amdgcn_readlane(slot[q], v & 63);
                     double p[SQ];
 #pragma unroll
-                    for (int q = 0; q < SQ; ++q) p[q] = slot_used(q) ? P.at(k, lane + 64 * q) : 0.0;
+                    for (int q = 0; q < SQ; ++q) {
+                        p[q] = P.at(k, kc[q]);
+                        p[q] = slot_used(q) ? p[q] : 0.0;
+                    }
+                    double wk = 0.0;
+#pragma unroll
+                    for (int q = 0; q < SQ; ++q)
+                        if ((k >> 6) == q) wk = lane_value(w[q], k & 63);
                     double pkk = 0.0;
 #pragma unroll
                     for (int q = 0; q < SQ; ++q)
@@ -540,10 +547,7 @@ __global__ __launch_bounds__(256) void lars_pos_kernel(const LarsArgs a) {
                         for (int u4 = 0; u4 < 4; ++u4) {
                             pi[u4] = u4 < n ? lane_value(p[qi], pos[u4]) : 0.0;
 #pragma unroll
-                            for (int q = 0; q < SQ; ++q) {
-                                const int i = 64 * qi + pos[u4], kk = lane + 64 * q;
-                                pv[u4][q] = (u4 < n && slot_used(q) && P.mine(i, kk)) ? P.at(i, kk) : 0.0;
-                            }
+                            for (int q = 0; q < SQ; ++q) pv[u4][q] = P.at(64 * qi + pos[u4], kc[q]);
                         }
 #pragma unroll
                         for (int u4 = 0; u4 < 4; ++u4)
@@ -554,13 +558,13 @@ __global__ __launch_bounds__(256) void lars_pos_kernel(const LarsArgs a) {
                                     P.at(i, kk) = pv[u4][q] - (pi[u4] * p[q]) * pinv;
                             }
                     });
-                    // its correlation, recomputed from the data (:889)
+                    // inverse . 1 without the atom: w - p w_k / p_kk (zero in its own slot)
+#pragma unroll
+                    for (int q = 0; q < SQ; ++q) w[q] = slot_used(q) ? w[q] - p[q] * (wk * pinv) : 0.0;
+                    // its correlation, recomputed from the data (:889); coefficients of lanes beyond r are zero
                     double dot = 0.0;
 #pragma unroll
-                    for (int q = 0; q < Q; ++q) {
-                        const int j = lane + 64 * q;
-                        if (j < r) dot += G[(size_t)v * r + j] * coef[q];
-                    }
+                    for (int q = 0; q < Q; ++q) dot += G[(size_t)v * r + jc[q]] * coef[q];
                     dot = uni(wave_sum(dot));
 #pragma unroll
                     for (int q = 0; q < Q; ++q)
@@ -572,8 +576,6 @@ __global__ __launch_bounds__(256) void lars_pos_kernel(const LarsArgs a) {
                     ++n_drops;
                     pass_fence();
                 }
-                pass_fence();
-                column_sums();
             }
         }
         if (overflow) {
