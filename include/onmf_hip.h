@@ -334,7 +334,7 @@ int onmf_ndl_accumulate_edges(onmf_ctx* ctx, int n_nodes, int k, int n_patches, 
  *                 exactly where NumPy would be after np.random.rand(n)
  * Synchronises `stream` (it returns host data).  With a jump table (onmf_numpy_set_jump_table: rows j = 1..n
  * hold x^(j * chunk_words - 1) modulo the generator's minimal polynomial, 624 words each, computed by
- * onmf_ontf_ndl_amd/mt_jump.py) chunks of chunk_words = 262 080 stream words are produced by as many
+ * onmf_ontf_ndl_amd/mt_jump.py) chunks of chunk_words = 131 040 stream words are produced by as many
  * workgroups at once; without one, chunk after chunk by a single workgroup.  Same output either way.
  */
 int onmf_numpy_set_jump_table(onmf_ctx* ctx, const uint32_t* table_host, int rows, long long chunk_words);

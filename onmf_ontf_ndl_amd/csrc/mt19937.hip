@@ -17,11 +17,12 @@
 
 #include <algorithm>
 #include <cstring>
+#include <vector>
 
 namespace {
 
 constexpr int MTN = 624, MTM = 397, MT_DEGREE = 19937;
-constexpr int MT_CHUNK_BLOCKS = 420;
+constexpr int MT_CHUNK_BLOCKS = 210;
 constexpr long long MT_CHUNK_WORDS = (long long)MTN * MT_CHUNK_BLOCKS;
 constexpr int MT_HEAD_BLOCKS = 33;                    // 33 * 624 = 20 592 >= 19 937 + 623
 constexpr int MT_HEAD_WORDS = MT_HEAD_BLOCKS * MTN;
@@ -68,38 +69,84 @@ __global__ __launch_bounds__(MT_THREADS) void mt_head_kernel(const uint32_t* __r
     }
 }
 
-// blocks[c] (c = 1 + blockIdx.x) = y[c * chunk .. c * chunk + 623] from table row c - 1 = x^(c * chunk - 1) mod phi
-__global__ __launch_bounds__(MT_THREADS) void mt_jump_kernel(const uint32_t* __restrict__ Y,
-                                                              const uint32_t* __restrict__ table,
-                                                              uint32_t* __restrict__ blocks) {
-    extern __shared__ uint32_t lds[];
-    uint32_t* ys = lds;                          // MT_HEAD_WORDS
-    uint32_t* win = lds + MT_HEAD_WORDS;         // 624
+// blocks[c] (c = 1 + blockIdx.x) = y[c * chunk .. c * chunk + 623] from list c - 1: the positions i of the set
+// bits of x^(c * chunk - 1) mod phi, sorted by i & 3 into four classes and stored as i >> 2.  Within a class every
+// window starts at the same offset from a 16-byte boundary, so a thread that owns four consecutive words of
+// the (class-shifted) sum reads whole aligned quads: acc_a[k'] ^= ys[4m + k'] for k' = 4t .. 4t + 3, and the
+// window is win[k] = XOR_a acc_a[k + a].  Each class is padded to a multiple of 8 entries with MT_HEAD_WORDS / 4
+// (a zeroed stretch behind the head words); eight quads are in flight at a time.  The list is split over
+// MT_JUMP_GROUPS groups of three wavefronts (157 of 192 lanes own a quad).
+constexpr int MT_LIST_STRIDE = 10240;                 // entries per list (19937 bits, half of them set, and room)
+constexpr int MT_JUMP_GROUPS = 2;
+constexpr int MT_JUMP_THREADS = 192 * MT_JUMP_GROUPS;
+constexpr int MT_QUADS = 157;                         // ceil((624 + 3) / 4)
+constexpr int MT_ZERO_WORDS = 1024;
+
+__global__ __launch_bounds__(MT_JUMP_THREADS) void mt_jump_kernel(const uint32_t* __restrict__ Y,
+                                                                   const uint16_t* __restrict__ lists,
+                                                                   const int* __restrict__ counts,
+                                                                   uint32_t* __restrict__ blocks) {
+    extern __shared__ __align__(16) uint32_t lds[];
+    uint32_t* ys = lds;                                   // MT_HEAD_WORDS + MT_ZERO_WORDS zeros
+    uint32_t* win = lds + MT_HEAD_WORDS + MT_ZERO_WORDS;  // 640
+    uint16_t* lst = reinterpret_cast<uint16_t*>(win + 640);           // the chunk's list, later the partial sums
     const int tid = threadIdx.x;
-    const uint32_t* row = table + (size_t)blockIdx.x * MTN;
-    for (int k = tid; k < MT_HEAD_WORDS; k += MT_THREADS) ys[k] = Y[k];
+    const int grp = tid / 192, t = tid % 192;
+    const int* cnt = counts + 4 * blockIdx.x;             // entries per class, multiples of 8
+    const int total = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+    const uint16_t* mine = lists + (size_t)blockIdx.x * MT_LIST_STRIDE;
+    for (int k = tid; k < MT_HEAD_WORDS; k += MT_JUMP_THREADS) ys[k] = Y[k];
+    for (int k = tid; k < MT_ZERO_WORDS; k += MT_JUMP_THREADS) ys[MT_HEAD_WORDS + k] = 0u;
+    for (int k = tid; k < total / 2; k += MT_JUMP_THREADS)
+        reinterpret_cast<uint32_t*>(lst)[k] = reinterpret_cast<const uint32_t*>(mine)[k];
     __syncthreads();
-    uint32_t acc0 = 0, acc1 = 0, acc2 = 0;
-    const bool third = tid + 512 < MTN;
-    for (int wi = 0; wi < MTN; ++wi) {
-        uint32_t bits = __builtin_amdgcn_readfirstlane(row[wi]);
-        if (wi == MTN - 1) bits &= (1u << (MT_DEGREE - 32 * (MTN - 1))) - 1u;      // coefficients below x^19937
-        while (bits) {
-            const int i = 32 * wi + __builtin_ctz(bits);
-            bits &= bits - 1;
-            acc0 ^= ys[i + tid];
-            acc1 ^= ys[i + tid + 256];
-            if (third) acc2 ^= ys[i + tid + 512];
+    uint4 acc[4];
+    const bool owner = t < MT_QUADS;
+    const uint4* yq = reinterpret_cast<const uint4*>(ys) + (owner ? t : 0);
+    int seg = 0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        acc[a] = make_uint4(0u, 0u, 0u, 0u);
+        const int octs = cnt[a] / 8;                      // this group's share, in eights
+        const int lo = seg + 8 * (octs * grp / MT_JUMP_GROUPS), hi = seg + 8 * (octs * (grp + 1) / MT_JUMP_GROUPS);
+        for (int e = lo; e < hi; e += 8) {
+            const uint4 pk = *reinterpret_cast<const uint4*>(lst + e);  // same address in every lane of the group
+            const uint32_t w[4] = {pk.x, pk.y, pk.z, pk.w};
+            uint4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = yq[(w[u >> 1] >> (16 * (u & 1))) & 0xffff];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                acc[a].x ^= v[u].x;
+                acc[a].y ^= v[u].y;
+                acc[a].z ^= v[u].z;
+                acc[a].w ^= v[u].w;
+            }
         }
+        seg += cnt[a];
     }
-    win[tid] = acc0;
-    win[tid + 256] = acc1;
-    if (third) win[tid + 512] = acc2;
+    __syncthreads();                                      // the list is read; its room takes the partial sums
+    uint4* part = reinterpret_cast<uint4*>(lst);          // [group][class][MT_QUADS + 3 quads]
+    constexpr int PQ = MT_QUADS + 3;
+    if (owner) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) part[(grp * 4 + a) * PQ + t] = acc[a];
+    }
+    __syncthreads();
+    const uint32_t* pw = reinterpret_cast<const uint32_t*>(part);
+    for (int k = tid; k < MTN; k += MT_JUMP_THREADS) {
+        uint32_t x = 0;
+#pragma unroll
+        for (int g = 0; g < MT_JUMP_GROUPS; ++g)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) x ^= pw[(g * 4 + a) * PQ * 4 + k + a];
+        win[k] = x;
+    }
     __syncthreads();
     // the window is one word early: [y[J-1] (top bit right), y[J], ..., y[J+622]]; the block wanted is
     // y[J .. J+623], whose last word follows from the recurrence
     uint32_t* out = blocks + (size_t)(blockIdx.x + 1) * MTN;
-    for (int k = tid; k < MTN - 1; k += MT_THREADS) out[k] = win[k + 1];
+    for (int k = tid; k < MTN - 1; k += MT_JUMP_THREADS) out[k] = win[k + 1];
     if (tid == 0) out[MTN - 1] = mt_mix(win[0], win[1], win[MTM]);
 }
 
@@ -161,14 +208,17 @@ __global__ __launch_bounds__(MT_THREADS) void mt_fill_kernel(const MtFillArgs a)
 
 }  // namespace
 
-// Device buffers of the generator (onmf_ctx::mt): [table rows*624 | Y head | blocks (rows+1)*624 | final 625+pad |
-// carry 624 | state in 624]
+// Device buffers of the generator (onmf_ctx::mt), in 32-bit words:
+// [lists rows * MT_LIST_STRIDE / 2 | counts rows * 4 | Y head | blocks (rows+1)*624 | final 640 | carry 624]
+static size_t mt_list_words(int rows) { return (size_t)rows * (MT_LIST_STRIDE / 2); }
+static size_t mt_count_words(int rows) { return (size_t)rows * 4; }
 int launch_numpy_rand(onmf_ctx* c, const uint32_t* key_host, int pos, size_t n, float* out, uint32_t* key_out_host,
                       int* pos_out, hipStream_t s) {
     const int rows = c->mt_rows;
     const int per_round = rows + 1;                         // chunks one round can start at once
-    const size_t off_table = 0;
-    const size_t off_y = off_table + (size_t)rows * MTN;
+    const size_t off_lists = 0;
+    const size_t off_counts = off_lists + mt_list_words(rows);
+    const size_t off_y = off_counts + mt_count_words(rows);
     const size_t off_blocks = off_y + MT_HEAD_WORDS;
     const size_t off_final = off_blocks + (size_t)per_round * MTN;
     const size_t off_carry = off_final + 640;
@@ -181,7 +231,7 @@ int launch_numpy_rand(onmf_ctx* c, const uint32_t* key_host, int pos, size_t n, 
     memcpy(pin, key_host, MTN * sizeof(uint32_t));
     HIP_TRY(c, hipMemcpyAsync(base + off_blocks, pin, MTN * sizeof(uint32_t), hipMemcpyHostToDevice, s));
     static LdsLimit lds_limit;
-    const size_t jump_lds = (size_t)(MT_HEAD_WORDS + MTN) * sizeof(uint32_t);
+    const size_t jump_lds = (size_t)(MT_HEAD_WORDS + MT_ZERO_WORDS + 640) * sizeof(uint32_t) + MT_LIST_STRIDE * sizeof(uint16_t);
     const long long end = (long long)pos + 2 * (long long)n;
     const long long chunks_total = n > 0 ? (end + MT_CHUNK_WORDS - 1) / MT_CHUNK_WORDS : 0;
     long long done = 0;
@@ -193,8 +243,9 @@ int launch_numpy_rand(onmf_ctx* c, const uint32_t* key_host, int pos, size_t n, 
         if (nc > 1) {
             hipLaunchKernelGGL(mt_head_kernel, dim3(1), dim3(MT_THREADS), 0, s, base + off_blocks, base + off_y);
             ONMF_TRY(onmf_raise_lds_limit(c, lds_limit, (const void*)mt_jump_kernel, jump_lds));
-            hipLaunchKernelGGL(mt_jump_kernel, dim3(nc - 1), dim3(MT_THREADS), jump_lds, s, base + off_y,
-                               base + off_table, base + off_blocks);
+            hipLaunchKernelGGL(mt_jump_kernel, dim3(nc - 1), dim3(MT_JUMP_THREADS), jump_lds, s, base + off_y,
+                               reinterpret_cast<const uint16_t*>(base + off_lists),
+                               reinterpret_cast<const int*>(base + off_counts), base + off_blocks);
         }
         MtFillArgs a;
         a.blocks = base + off_blocks;
@@ -223,10 +274,31 @@ int launch_numpy_rand(onmf_ctx* c, const uint32_t* key_host, int pos, size_t n, 
 }
 
 int numpy_rand_setup(onmf_ctx* c, const uint32_t* table_host, int rows, hipStream_t s) {
-    const size_t total = (size_t)rows * MTN + MT_HEAD_WORDS + (size_t)(rows + 1) * MTN + 640 + MTN;
+    const size_t total = mt_list_words(rows) + mt_count_words(rows) + MT_HEAD_WORDS + (size_t)(rows + 1) * MTN + 640 + MTN;
     ONMF_TRY(onmf_reserve(c, c->mt, total * sizeof(uint32_t), "MT19937 buffers"));
     if (rows > 0) {
-        HIP_TRY(c, hipMemcpyAsync(c->mt.p, table_host, (size_t)rows * MTN * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        // the rows' set bits as lists of positions (what the jump kernel walks): by position & 3, then
+        // ascending, stored as position >> 2, each class padded to a multiple of 8
+        std::vector<uint16_t> lists((size_t)rows * MT_LIST_STRIDE, (uint16_t)(MT_HEAD_WORDS / 4));
+        std::vector<int> counts(mt_count_words(rows), 0);
+        for (int j = 0; j < rows; ++j) {
+            int n = 0;
+            for (int a = 0; a < 4; ++a) {
+                const int start = n;
+                for (int i = a; i < MT_DEGREE; i += 4)
+                    if ((table_host[(size_t)j * MTN + (i >> 5)] >> (i & 31)) & 1u) {
+                        if (n >= MT_LIST_STRIDE - 32)
+                            return onmf_fail(c, ONMF_ERR_ARG, "numpy_rand: table row %d has too many bits", j);
+                        lists[(size_t)j * MT_LIST_STRIDE + n++] = (uint16_t)(i >> 2);
+                    }
+                n = start + ((n - start + 7) & ~7);
+                counts[4 * j + a] = n - start;
+            }
+        }
+        uint32_t* base = (uint32_t*)c->mt.p;
+        HIP_TRY(c, hipMemcpyAsync(base, lists.data(), lists.size() * sizeof(uint16_t), hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(base + mt_list_words(rows), counts.data(), counts.size() * sizeof(int),
+                                  hipMemcpyHostToDevice, s));
         HIP_TRY(c, hipStreamSynchronize(s));
     }
     c->mt_rows = rows;

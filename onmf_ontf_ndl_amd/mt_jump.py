@@ -26,9 +26,9 @@ import numpy as np
 N, M = 624, 397
 DEGREE = 19937
 UPPER, LOWER, MATRIX_A = 0x80000000, 0x7FFFFFFF, 0x9908B0DF
-CHUNK_BLOCKS = 420                       # blocks of 624 words per chunk of the device generator
+CHUNK_BLOCKS = 210                       # blocks of 624 words per chunk of the device generator
 CHUNK_WORDS = N * CHUNK_BLOCKS
-TABLE_CHUNKS = 128                       # jumps held: up to 128 chunks (33.5 M words) per round
+TABLE_CHUNKS = 256                       # jumps held: up to 256 chunks (33.5 M words) per round
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
