@@ -375,6 +375,19 @@ __global__ __launch_bounds__(64 * WPG) void sweep_tile_kernel(
             // part of those addresses is recomputed per use.)
             typedef __attribute__((address_space(3))) const float lds_cfloat;
             auto read_a = [&](int J, float (&a)[4]) {
+#ifdef ONMF_DIAG_DIRECT_ONLY
+                // Counter diagnostics only (wrong results): blocks above the diagonal are read by rows like the
+                // others, which takes the transposed reads - four ds_read_b32 per lane, issued as two
+                // ds_read2_b32, the source of nearly all LDS bank-conflict cycles of the half layout - out of
+                // the kernel.  The kernel is not measurably faster without them: they hide behind the matrix
+                // and vector work.
+                if (HALF && J > K) {
+                    const float4 v = *reinterpret_cast<const float4*>(
+                        Gs + blk_index<NB, HALF>(J, K) * 256 + c * 16 + 4 * (g ^ sw_c));
+                    a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w;
+                    return;
+                }
+#endif
                 if (!HALF || J <= K) {
                     const float4 v = *reinterpret_cast<const float4*>(
                         Gs + blk_index<NB, HALF>(K, J) * 256 + c * 16 + 4 * (g ^ sw_c));
