@@ -40,6 +40,7 @@ WORKLOADS = {
     "c3-ntf-100": (1200, 100, 100),      # the batch the reference's main uses
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3
+PEAK_HBM_GBPS = 8000.0
 SWEEPS = 10
 SWEEP_KERNEL_SOURCE = os.path.join(ROOT, "onmf_ontf_ndl_amd", "csrc", "sweep_tile.h")
 
@@ -151,6 +152,40 @@ def measured_traffic(d, r, b, sweeps_per_launch):
     if rec.get("kernel_source_sha256") != sha:
         return None                      # the kernel changed since the counters were read
     return rec["hbm_bytes_first_read"] + sweeps_per_launch * rec["hbm_bytes_per_sweep_in_launch"]
+
+
+def measured_step_hbm(d, r, b, ms_per_step):
+    """Whole-step HBM figure: bytes per step over ALL kernels of a step, from the committed FETCH_SIZE / WRITE_SIZE
+    passes of this same command (profiles/*_step_hbm_traffic.json, made by tools/step_hbm.py), divided by
+    this run's time per step.  None when no record for this shape is there; `sources_unchanged` tells whether
+    the kernels' sources are the ones the counters were read from."""
+    prof = os.path.join(ROOT, "profiles")
+    try:
+        names = sorted(n for n in os.listdir(prof) if n.endswith("_step_hbm_traffic.json"))
+        with open(os.path.join(prof, names[-1])) as f:
+            rec = json.load(f)
+        if rec.get("shape") != {"d": d, "r": r, "b": b}:
+            return None
+        sha = csrc_sha256()
+    except (OSError, ValueError, IndexError, KeyError):
+        return None
+    by = rec["hbm_bytes_per_step"]
+    return {"bytes_per_step": by, "achieved": by / (ms_per_step * 1e-3) / 1e9, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+            "frac": by / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBPS,
+            "algorithmic_bytes_per_step": rec.get("algorithmic_bytes_per_step"),
+            "source": "profiles/" + names[-1], "sources_unchanged": rec.get("csrc_sha256") == sha}
+
+
+def csrc_sha256():
+    """One hash over the library's sources (names and contents, in name order)."""
+    src = os.path.join(ROOT, "onmf_ontf_ndl_amd", "csrc")
+    h = hashlib.sha256()
+    for n in sorted(os.listdir(src)):
+        if n.endswith((".hip", ".h", ".cpp")):
+            h.update(n.encode())
+            with open(os.path.join(src, n), "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()
 
 
 def parse_args(argv=None):
@@ -364,6 +399,10 @@ def main():
                                "traffic": measured_traffic(d, r, b, sweeps_per_launch),
                                "avg_launch_ms": avg_ms, "launches": sweep_launches,
                                "sweeps_per_launch": sweeps_per_launch}
+        if world == 1 and not ntf:
+            hb = measured_step_hbm(d, r, b, ms)
+            if hb is not None:
+                out["step_hbm"] = hb
         if world == 1 and args.workload == "headline" and not args.no_also:
             # the small reference-scale case (d=1024, r=64, batch=8192) beside the headline number: it is
             # bound by launches and the host's part in borderline stopping tests, not by the kernels

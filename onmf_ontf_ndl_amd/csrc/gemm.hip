@@ -217,10 +217,45 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmParams p) {
     float* As = lds;
     float* Bs = lds + 2 * TILE_ELEMS;
 
-    const int tile = blockIdx.x;
+    // Workgroups go to the 8 XCDs in turn (linear id mod 8), and each XCD has its own L2.  Workgroups that
+    // read the same operand slice are therefore given ids 8 apart - same XCD, next to each other in time -
+    // so that the slice crosses the fabric once instead of once per XCD that happens to want it:
+    //  - split contractions: all tiles of one slab (they share the slab's slices of A and B);
+    //  - unsplit products with several rows of tiles: the tiles of one column of tiles (they share B's).
+    // Which workgroup computes which tile does not change any result.
+    // MEASURED AND NOT ADOPTED (diagnostic builds only, -DONMF_GEMM_XCD_MAP): at d=1024 r=256 b=65536 the
+    // bytes that cross the fabric per step fall from 4.35 to 3.17 GB (aggregate pair 957 -> 390 MB per
+    // launch, W^T X 548 -> 300 MB), and both products get SLOWER (aggregate pair 318 -> 333 us, W^T X
+    // 234 -> 240 us, step 1.587 -> 1.605 ms): they are bound by the matrix pipe, and workgroups of one XCD
+    // that walk the same slice in step all miss on the same lines at the same time.
+#ifdef ONMF_GEMM_XCD_MAP
+    int tile = blockIdx.x, z = blockIdx.z;
+    {
+        const int G = gridDim.x, S = gridDim.z;
+        if (S >= 8) {
+            const int L = tile + G * z, full = (S >> 3) << 3;
+            if (L < full * G) {
+                const int slot = L >> 3;
+                z = (slot / G) * 8 + (L & 7);
+                tile = slot % G;
+            }
+        } else if (S == 1) {
+            const int tm = G / p.tiles_n;                 // rows of tiles
+            const int full = (p.tiles_n >> 3) << 3;       // columns of tiles that go in eights
+            if (tm > 1 && tile < full * tm) {
+                const int grp = tile / (8 * tm), rem = tile - grp * 8 * tm;
+                tile = (rem >> 3) * p.tiles_n + grp * 8 + (rem & 7);
+            } else if (tm > 1) {
+                const int rest = p.tiles_n - full, t2 = tile - full * tm;
+                tile = (t2 / rest) * p.tiles_n + full + t2 % rest;
+            }
+        }
+    }
+#else
+    const int tile = blockIdx.x, z = blockIdx.z;
+#endif
     const int m0 = (tile / p.tiles_n) * BM;
     const int n0 = (tile % p.tiles_n) * BN;
-    const int z = blockIdx.z;
     const int kbeg = z * p.k_per_split;
     const int kend = min(p.K, kbeg + p.k_per_split);
 
