@@ -264,7 +264,8 @@ int launch_ndl_edge_accumulate(int n, int k, int T, const int* emb_trace, const 
                                float* count, hipStream_t s);
 
 // Stopping-test screen: state layout and kernels.
-// words of onmf_ctx::host_events that the LARS coder's last kernel writes: slots used, r, columns recoded
+// first of the eight words of onmf_ctx::host_events that the LARS coder's last kernel writes: most slots a column
+// used, r, columns recoded so far, columns that needed more than 16 / 32 / 48 / 64 slots, columns coded
 constexpr int ONMF_LARS_HOST_WORDS = 4;
 constexpr int SCREEN_MAX_SWEEPS = 64;
 constexpr int SCREEN_REPL = 8;       // replicas of the sweep kernel's accumulators (atomic contention)

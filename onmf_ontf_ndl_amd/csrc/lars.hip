@@ -260,6 +260,7 @@ __global__ __launch_bounds__(256) void lars_pos_kernel(const LarsArgs a) {
     const double alpha_min = a.alpha / a.n_samples;
     const int n_cols = a.cols ? *a.n_cols : a.b;
     int peak_slots = 0;
+    int over16 = 0, over32 = 0, over48 = 0, over64 = 0;     // columns of this wave that needed more slots than that
 
     for (int ci = blockIdx.x * wpg + wave; ci < n_cols; ci += gridDim.x * wpg) {
         const int col = a.cols ? a.cols[ci] : ci;
@@ -289,6 +290,7 @@ __global__ __launch_bounds__(256) void lars_pos_kernel(const LarsArgs a) {
         // two events in the library; the bound makes sure that every wave leaves the loop whatever the data)
         int trips_left = a.max_iter + 2 * r + 8;
         bool drop = false, overflow = false;
+        int col_peak = 0;
         double alpha = 0.0, prev_alpha = 0.0;
 
         auto slot_used = [&](int q) -> bool { return (used[q] >> lane) & 1ull; };
@@ -385,7 +387,7 @@ __global__ __launch_bounds__(256) void lars_pos_kernel(const LarsArgs a) {
                     overflow = true;
                     break;
                 }
-                peak_slots = max(peak_slots, knew + 1);
+                col_peak = max(col_peak, knew + 1);
                 // inverse += u u^T / s over the used slots; the new slot's row and column
                 for_used<4>(used, [&](int qi, const int (&pos)[4], int n) {
                     double pv[4][SQ], ui[4];
@@ -584,6 +586,12 @@ __global__ __launch_bounds__(256) void lars_pos_kernel(const LarsArgs a) {
                 a.overflow[at] = col;
             }
         } else {
+            // (a column that ran out of room is counted where it is coded: in the second launch)
+            peak_slots = max(peak_slots, col_peak);
+            over16 += col_peak > 16;
+            over32 += col_peak > 32;
+            over48 += col_peak > 48;
+            over64 += col_peak > 64;
 #pragma unroll
             for (int q = 0; q < Q; ++q) {
                 const int j = lane + 64 * q;
@@ -599,21 +607,30 @@ __global__ __launch_bounds__(256) void lars_pos_kernel(const LarsArgs a) {
         }
         pass_fence();
     }
-    if (lane == 0 && peak_slots > 0)
+    if (lane == 0 && peak_slots > 0) {
         __hip_atomic_fetch_max(a.meta + 1, peak_slots, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (over16) __hip_atomic_fetch_add(a.meta + 2, over16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (over32) __hip_atomic_fetch_add(a.meta + 3, over32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (over48) __hip_atomic_fetch_add(a.meta + 4, over48, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (over64) __hip_atomic_fetch_add(a.meta + 5, over64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
-// behind the launches of a call: the most slots a column used goes to host memory the device can write (the
-// next call sizes its first launch by it), and the two words are cleared for that call
-__global__ void lars_publish_kernel(int* meta, int* host_words, int r) {
+// behind the launches of a call: the most slots a column used, and how many columns needed more than 16, 32, 48
+// and 64, go to host memory the device can write (the next call sizes its first launch by them), and the
+// device words are cleared for that call
+__global__ void lars_publish_kernel(int* meta, int* host_words, int r, int b) {
     host_words[0] = meta[1];
     host_words[1] = r;
     host_words[2] += meta[0];          // columns coded by a second launch since the context was created
-    meta[0] = 0;
-    meta[1] = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) host_words[3 + i] = meta[2 + i];
+    host_words[7] = b;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) meta[i] = 0;
 }
 
-constexpr int LARS_HOST_WORDS = ONMF_LARS_HOST_WORDS;      // first of the three words above in onmf_ctx::host_events
+constexpr int LARS_HOST_WORDS = ONMF_LARS_HOST_WORDS;      // first of the words above in onmf_ctx::host_events
 
 template <int Q, int SQ, bool P_LDS>
 int launch_lars_form(onmf_ctx* c, LarsArgs a, int n_cap, bool second, hipStream_t s) {
@@ -665,21 +682,26 @@ int launch_lars_q(onmf_ctx* c, const LarsArgs& a0, hipStream_t s) {
     ONMF_TRY(onmf_reserve(c, c->lars_overflow, (size_t)a.b * sizeof(int), "LARS overflow list"));
     a.meta = (int*)c->lars_meta.p;
     a.overflow = (int*)c->lars_overflow.p;
-    // the most slots a column of the previous call used (same r): the first launch gets a quarter more,
-    // which lets several waves per SIMD be resident; columns that need more go to the second launch
+    // How many columns of the previous call (same r) needed more than 16, 32, 48, 64 slots: the first launch
+    // gets the smallest of these capacities that all but a few columns (1 in 64) would have fitted in - small
+    // inverses let several waves per SIMD be resident - and the columns that need more go to the second launch,
+    // which has room for all r atoms.  A first call, with nothing to go by, tries 64.
     volatile int* hw = c->host_events + LARS_HOST_WORDS;
-    const int hint = (hw[1] == r && c->lars_hint_ok) ? hw[0] : -1;
+    const bool have = hw[1] == r && c->lars_hint_ok && hw[7] > 0;
     int n_cap = r;
     if (c->lars_slots > 0) {
         n_cap = c->lars_slots < r ? c->lars_slots : r;
         if (n_cap > 64 && n_cap < r) n_cap = 64;
-    } else if (hint >= 0) {
-        const int want = hint + hint / 4 + 4;
-        for (int cand : {16, 32, 48, 64})
-            if (want <= cand && cand < r) {
-                n_cap = cand;
+    } else if (have) {
+        const int few = hw[7] / 64;
+        const int caps[4] = {16, 32, 48, 64};
+        for (int i = 0; i < 4; ++i)
+            if (hw[3 + i] <= few && caps[i] < r) {
+                n_cap = caps[i];
                 break;
             }
+    } else if (r > 64) {
+        n_cap = 64;
     }
     const bool full_fits = lars_lds_bytes(r) <= 160 * 1024;
     if (n_cap < r) {
@@ -694,7 +716,7 @@ int launch_lars_q(onmf_ctx* c, const LarsArgs& a0, hipStream_t s) {
     } else {
         ONMF_TRY((launch_lars_form<Q, Q, false>(c, a, r, false, s)));
     }
-    hipLaunchKernelGGL(lars_publish_kernel, dim3(1), dim3(1), 0, s, a.meta, c->host_events_dev + LARS_HOST_WORDS, r);
+    hipLaunchKernelGGL(lars_publish_kernel, dim3(1), dim3(1), 0, s, a.meta, c->host_events_dev + LARS_HOST_WORDS, r, a.b);
     if (hipGetLastError() != hipSuccess) return onmf_fail(c, ONMF_ERR_HIP, "LARS coder: launch failed");
     c->lars_hint_ok = true;
     return ONMF_OK;

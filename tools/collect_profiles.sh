@@ -18,6 +18,6 @@ for w in c1 c2 c3 c4 c5; do
 done
 timeout -k 10 300 python3 bench.py --stopping-diff 0 --no-cpu-baseline --no-also --no-parity >> "$OUT/workloads.txt" 2>> "$OUT/workloads.err" || exit 1
 for w in c3-ntf-100 c3-ntf; do
-    timeout -k 10 400 python3 bench.py --workload $w --steps 10 --warmup 3 >> "$OUT/workloads.txt" 2>> "$OUT/workloads.err" || exit 1
+    timeout -k 10 400 python3 bench.py --workload $w >> "$OUT/workloads.txt" 2>> "$OUT/workloads.err" || exit 1
 done
 echo collected

@@ -6,8 +6,9 @@ bench.py itself (FETCH_SIZE in one run, WRITE_SIZE in another; tools/run_step_hb
 
 FETCH_SIZE is in KiB and reports half of the bytes on gfx950 (doubled here, as for the sweep kernel's own
 record); WRITE_SIZE is in KiB as read.  Kernels of the library and the runtime's buffer copies are counted;
-torch's kernels (the synthetic batch, drawn once before the steps) are not.  Every step of the run does the
-same work, warm-up steps included, so the totals are divided by steps + warm-up.
+torch's kernels (the synthetic batch, drawn once before the steps) are not.  Each counter is read from a short and
+a long run of the same command; the difference divided by the difference in steps is what one step moves (the
+set-up work of a run - first dictionary, probes, warm-up of the stopping test - drops out).
 """
 import csv
 import glob
@@ -40,9 +41,13 @@ def totals(path, counter):
 def main():
     src, out = sys.argv[1], sys.argv[2]
     meta = json.load(open(os.path.join(src, "run.json")))
-    steps = meta["steps"] + meta["warmup"]
+    steps = meta["steps_long"] - meta["steps_short"]
     d, r, b = bench.WORKLOADS["headline"]
-    fetch, write = totals(os.path.join(src, "fetch"), "FETCH_SIZE"), totals(os.path.join(src, "write"), "WRITE_SIZE")
+
+    def diff(name, counter):
+        lo, hi = totals(os.path.join(src, name + "_short"), counter), totals(os.path.join(src, name + "_long"), counter)
+        return {k: [hi[k][0] - lo.get(k, [0.0, 0])[0], hi[k][1] - lo.get(k, [0.0, 0])[1]] for k in hi}
+    fetch, write = diff("f", "FETCH_SIZE"), diff("w", "WRITE_SIZE")
     per_kernel = {}
     for k in sorted(set(fetch) | set(write)):
         rd = 2048.0 * fetch.get(k, [0.0, 0])[0] / steps
