@@ -22,7 +22,6 @@
 
 namespace {
 
-constexpr int BM = 128;
 constexpr int BN = 128;
 constexpr int BK = 32;
 constexpr int NTHREADS = 256;
@@ -60,19 +59,31 @@ struct GemmParams {
     int ldb2, n1, n1p, vecB2;
 };
 
-// Global -> registers for one BK x 128 operand tile (4 float4 per thread).
-// KMAJ (memory [k][x]): thread t takes k = (t & 7) + 8p, x = 4 (t >> 3) .. +3 - a wave reads 8 rows
-// of 128 contiguous bytes.  Otherwise (memory [x][k]): x = (t >> 3) + 32p, k = 4 (t & 7) .. +3.
-template <bool KMAJ>
+// Which element of a BK x ROWS operand tile (ROWS = 128 or 64 rows of the output it feeds) thread t handles
+// as its part p (ROWS / 32 float4 per thread).
+// KMAJ (memory [k][x]): x = 4 chunk .. +3 with ROWS / 4 chunks per k-row - a wave reads 8 (or 4) k-rows
+// of 128 (or 256) contiguous bytes; k = (t & 7) + 8 p for 128 rows, (t & 7) + 8 (2p + (t >> 7)) for 64.
+// Otherwise (memory [x][k]): x = (t >> 3) + 32p, k = 4 (t & 7) .. +3.
+template <bool KMAJ, int ROWS>
+__device__ __forceinline__ int part_k(int t, int p) {
+    return KMAJ ? (t & 7) + 8 * (ROWS == 128 ? p : 2 * p + (t >> 7)) : (t & 7) * 4;
+}
+template <bool KMAJ, int ROWS>
+__device__ __forceinline__ int part_x(int t, int p) {
+    return KMAJ ? 4 * ((t >> 3) & (ROWS / 4 - 1)) : (t >> 3) + 32 * p;
+}
+
+// Global -> registers for one BK x ROWS operand tile, checked element by element.
+template <bool KMAJ, int ROWS>
 __device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, int xdim, int x0,
                                           int k0, int kend, int vec_ok, float4 (&rg)[4]) {
     const int t = threadIdx.x;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < ROWS / 32; ++p) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int k = k0 + part_k<KMAJ, ROWS>(t, p);
+        const int x = x0 + part_x<KMAJ, ROWS>(t, p);
         if (KMAJ) {
-            const int k = k0 + (t & 7) + 8 * p;
-            const int x = x0 + (t >> 3) * 4;
             if (k < kend) {
                 const float* src = P + (size_t)k * ld + x;
                 if (vec_ok && x + 3 < xdim) {
@@ -85,8 +96,6 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, i
                 }
             }
         } else {
-            const int x = x0 + (t >> 3) + 32 * p;
-            const int k = k0 + (t & 7) * 4;
             if (x < xdim) {
                 const float* src = P + (size_t)x * ld + k;
                 if (vec_ok && k + 3 < kend) {
@@ -103,43 +112,25 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, i
     }
 }
 
-// Registers -> LDS tile S[x][k] (swizzled).
-template <bool KMAJ>
-__device__ __forceinline__ void store_tile(float* __restrict__ S, const float4 (&rg)[4]) {
-    const int t = threadIdx.x;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        if (KMAJ) {
-            const int k = (t & 7) + 8 * p;
-            const int x = (t >> 3) * 4;
-            S[lds_off(x + 0, k)] = rg[p].x;
-            S[lds_off(x + 1, k)] = rg[p].y;
-            S[lds_off(x + 2, k)] = rg[p].z;
-            S[lds_off(x + 3, k)] = rg[p].w;
-        } else {
-            const int x = (t >> 3) + 32 * p;
-            const int k = (t & 7) * 4;
-            *reinterpret_cast<float4*>(S + lds_off(x, k)) = rg[p];
-        }
-    }
-}
-
-// One quarter (part p) of store_tile.
-template <bool KMAJ>
+// One part of: registers -> LDS tile S[x][k] (swizzled).
+template <bool KMAJ, int ROWS>
 __device__ __forceinline__ void store_part(float* __restrict__ S, const float4& v, int p) {
     const int t = threadIdx.x;
+    const int k = part_k<KMAJ, ROWS>(t, p), x = part_x<KMAJ, ROWS>(t, p);
     if (KMAJ) {
-        const int k = (t & 7) + 8 * p;
-        const int x = (t >> 3) * 4;
         S[lds_off(x + 0, k)] = v.x;
         S[lds_off(x + 1, k)] = v.y;
         S[lds_off(x + 2, k)] = v.z;
         S[lds_off(x + 3, k)] = v.w;
     } else {
-        const int x = (t >> 3) + 32 * p;
-        const int k = (t & 7) * 4;
         *reinterpret_cast<float4*>(S + lds_off(x, k)) = v;
     }
+}
+
+template <bool KMAJ, int ROWS>
+__device__ __forceinline__ void store_tile(float* __restrict__ S, const float4 (&rg)[4]) {
+#pragma unroll
+    for (int p = 0; p < ROWS / 32; ++p) store_part<KMAJ, ROWS>(S, rg[p], p);
 }
 
 // Tile source.  Interior tiles of aligned operands come through a buffer descriptor: the per-thread
@@ -148,8 +139,9 @@ __device__ __forceinline__ void store_part(float* __restrict__ S, const float4& 
 // and unaligned operands take the checked path.
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-template <bool KMAJ>
+template <bool KMAJ, int ROWS>
 struct TileSource {
+    static constexpr int NP = ROWS / 32;      // float4 per thread and tile
     const float* P;
     int ld, xdim, x0, kbeg, kend, vec_ok;
     bool fast;
@@ -163,11 +155,21 @@ struct TileSource {
         const int t = threadIdx.x;
         const size_t rows = KMAJ ? (size_t)kdim : (size_t)xdim;
         const size_t bytes = rows * (size_t)ld * sizeof(float);
-        fast = vec_ok && (x0 + 128 <= xdim) && bytes < 0xfffff000ull;
+        // A tile that reaches beyond the operand's last row / column (x >= xdim) stays on this path when the
+        // buffer is small enough for an offset that is out of range by itself: lanes whose x is beyond the
+        // edge get that offset and the hardware's range check hands them zeros - no branch, no select.
+        // (Operands narrower than a tile - r = 16 ... 100 - would otherwise take the checked path for every
+        // tile of every product.)  [k][x] memory: a lane's four x must be all inside or all outside.
+        const bool whole = x0 + ROWS <= xdim;
+        const bool maskable = bytes < 0x7ffff000ull && (!KMAJ || (xdim & 3) == 0);
+        fast = vec_ok && bytes < 0xfffff000ull && (whole || maskable);
         rs = __builtin_amdgcn_make_buffer_rsrc((void*)P, 0, (unsigned)(fast ? bytes : 0), 0x00020000);
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
-            voff[p] = KMAJ ? (((t & 7) + 8 * p) * ld + (t >> 3) * 4) * 4 : (((t >> 3) + 32 * p) * ld + (t & 7) * 4) * 4;
+        for (int p = 0; p < NP; ++p) {
+            const int k = part_k<KMAJ, ROWS>(t, p), x = part_x<KMAJ, ROWS>(t, p);
+            voff[p] = KMAJ ? (k * ld + x) * 4 : (x * ld + k) * 4;
+            if (x0 + x >= xdim) voff[p] = (int)0x80000000u;
+        }
         soff0 = KMAJ ? (unsigned)(((size_t)kbeg * ld + x0) * 4) : (unsigned)(((size_t)x0 * ld + kbeg) * 4);
         sstep = KMAJ ? (unsigned)((size_t)BK * ld * 4) : (unsigned)(BK * 4);
     }
@@ -182,13 +184,13 @@ struct TileSource {
         if (SURE || (fast && k0 + BK <= kend)) {             // uniform
             const unsigned so = soff0 + (unsigned)tile * sstep;
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
+            for (int p = 0; p < NP; ++p) {
                 const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff[p], so, NT ? 2 : 0);
                 rg[p] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]),
                                     __uint_as_float(v[3]));
             }
         } else {
-            load_tile<KMAJ>(P, ld, xdim, x0, k0, kend, vec_ok, rg);
+            load_tile<KMAJ, ROWS>(P, ld, xdim, x0, k0, kend, vec_ok, rg);
         }
     }
     // one quarter of a whole tile of a `fast` source
@@ -205,17 +207,22 @@ __device__ unsigned long long g_wg_trace[4 * 65536];
 __device__ unsigned g_wg_trace_n;
 #endif
 
-template <bool A_KM, bool B_KN>
+// BMT: rows of the output tile, 128 or 64.  With 64 (products whose output has at most 64 rows: a 128-row tile
+// would spend half of its matrix instructions on rows of zeros) the four waves sit side by side, each on a
+// 64 x 32 block; the A tile is half as large and comes as two parts per thread instead of four.
+template <bool A_KM, bool B_KN, int BMT>
 __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmParams p) {
+    constexpr int AP = BMT / 32;                 // parts of the A tile per thread
+    constexpr int NJ = BMT == 128 ? 2 : 1;       // 32-column blocks per wave
     extern __shared__ __attribute__((aligned(16))) float lds[];
 #ifdef ONMF_TRACE_WG
     const unsigned long long trace_t0 = wall_clock64();
 #endif
     // layout: [A buf0][A buf1][B buf0][B buf1]
-    constexpr int A_STRIDE = TILE_ELEMS;
+    constexpr int A_STRIDE = BMT * BK;
     constexpr int B_STRIDE = TILE_ELEMS;
     float* As = lds;
-    float* Bs = lds + 2 * TILE_ELEMS;
+    float* Bs = lds + 2 * A_STRIDE;
 
     // Workgroups go to the 8 XCDs in turn (linear id mod 8), and each XCD has its own L2.  Workgroups that
     // read the same operand slice are therefore given ids 8 apart - same XCD, next to each other in time -
@@ -254,23 +261,23 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmParams p) {
 #else
     const int tile = blockIdx.x, z = blockIdx.z;
 #endif
-    const int m0 = (tile / p.tiles_n) * BM;
+    const int m0 = (tile / p.tiles_n) * BMT;
     const int n0 = (tile % p.tiles_n) * BN;
     const int kbeg = z * p.k_per_split;
     const int kend = min(p.K, kbeg + p.k_per_split);
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int wm = (wave >> 1) * 64;
-    const int wn = (wave & 1) * 64;
+    const int wm = BMT == 128 ? (wave >> 1) * 64 : 0;
+    const int wn = BMT == 128 ? (wave & 1) * 64 : wave * 32;
     const int l31 = lane & 31;
     const int lhi = lane >> 5;
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
@@ -281,8 +288,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmParams p) {
     // roles without copies.
     float4 ra[4], rb[4], ra2[4], rb2[4];
     const int ntiles = (kend - kbeg + BK - 1) / BK;
-    TileSource<A_KM> srcA;
-    TileSource<B_KN> srcB;
+    TileSource<A_KM, BMT> srcA;
+    TileSource<B_KN, 128> srcB;
     srcA.init(p.A, p.lda, p.M, p.K, m0, kbeg, kend, p.vecA);
     if (p.n1 > 0 && n0 >= p.n1p) srcB.init(p.B2, p.ldb2, p.N - p.n1p, p.K, n0 - p.n1p, kbeg, kend, p.vecB2);
     else srcB.init(p.B, p.ldb, p.n1 > 0 ? p.n1 : p.N, p.K, n0, kbeg, kend, p.vecB);
@@ -299,14 +306,14 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmParams p) {
             srcB.template load<true, true>(0, rb2);
             srcA.template load<false, true>(min(1, ntiles - 1), ra);
             srcB.template load<true, true>(min(1, ntiles - 1), rb);
-            store_tile<A_KM>(As, ra2);
-            store_tile<B_KN>(Bs, rb2);
+            store_tile<A_KM, BMT>(As, ra2);
+            store_tile<B_KN, 128>(Bs, rb2);
             __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0)
         } else if (ntiles > 0) {
             srcA.template load<false, false>(0, ra);
             srcB.template load<true, false>(0, rb);
-            store_tile<A_KM>(As, ra);
-            store_tile<B_KN>(Bs, rb);
+            store_tile<A_KM, BMT>(As, ra);
+            store_tile<B_KN, 128>(Bs, rb);
             if (ntiles > 1) {
                 srcA.template load<false, false>(1, ra);
                 srcB.template load<true, false>(1, rb);
@@ -334,7 +341,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmParams p) {
                 a0 = *reinterpret_cast<const float4*>(Ac + lds_off(wm + l31, k));
                 a1 = *reinterpret_cast<const float4*>(Ac + lds_off(wm + 32 + l31, k));
                 b0 = *reinterpret_cast<const float4*>(Bc + lds_off(wn + l31, k));
-                b1 = *reinterpret_cast<const float4*>(Bc + lds_off(wn + 32 + l31, k));
+                if (NJ == 2) b1 = *reinterpret_cast<const float4*>(Bc + lds_off(wn + 32 + l31, k));
             };
             float4 a0, a1, b0, b1, na0, na1, nb0, nb1;
             fetch(0, a0, a1, b0, b1);
@@ -342,8 +349,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmParams p) {
             for (int q = 0; q < BK / 8; ++q) {
                 if (q + 1 < BK / 8) fetch(q + 1, na0, na1, nb0, nb1);
                 if (!SURE && q == BK / 16 && t + 1 < ntiles) {
-                    store_tile<A_KM>(An, xa);
-                    store_tile<B_KN>(Bn, xb);
+                    store_tile<A_KM, BMT>(An, xa);
+                    store_tile<B_KN, 128>(Bn, xb);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
@@ -356,19 +363,19 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmParams p) {
                     // lasts (measured on this loop: 343 us with bursts, 318 us interleaved, 307 us with
                     // no memory instructions at all).
                     acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[j], bv0[j], acc[0][0], 0, 0, 0);
-                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[j], bv1[j], acc[0][1], 0, 0, 0);
-                    if (SURE && (q == 0 || q == BK / 16)) {
+                    if (NJ == 2) acc[0][NJ - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[j], bv1[j], acc[0][NJ - 1], 0, 0, 0);
+                    if (SURE && (q == 0 || q == BK / 16) && j < AP) {
                         __builtin_amdgcn_sched_barrier(0);
                         if (q == 0) srcA.template load_part<false>(tl, j, ya[j]);
-                        else store_part<A_KM>(An, xa[j], j);     // (last round: a tile nobody reads)
+                        else store_part<A_KM, BMT>(An, xa[j], j);     // (last round: a tile nobody reads)
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[j], bv0[j], acc[1][0], 0, 0, 0);
-                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[j], bv1[j], acc[1][1], 0, 0, 0);
+                    if (NJ == 2) acc[1][NJ - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[j], bv1[j], acc[1][NJ - 1], 0, 0, 0);
                     if (SURE && (q == 0 || q == BK / 16)) {
                         __builtin_amdgcn_sched_barrier(0);
                         if (q == 0) srcB.template load_part<true>(tl, j, yb[j]);
-                        else store_part<B_KN>(Bn, xb[j], j);
+                        else store_part<B_KN, 128>(Bn, xb[j], j);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -385,12 +392,19 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmParams p) {
             round(t + 1, ra2, rb2, ra, rb);
             // the accumulators stay in the accumulation registers across the loop edge (left alone, the
             // compiler carries them through vector registers: 128 copies per trip)
-            asm volatile("" : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[1][0]), "+a"(acc[1][1]));
+            if (NJ == 2) asm volatile("" : "+a"(acc[0][0]), "+a"(acc[0][NJ - 1]), "+a"(acc[1][0]), "+a"(acc[1][NJ - 1]));
+            else asm volatile("" : "+a"(acc[0][0]), "+a"(acc[1][0]));
         }
         if (t < ntiles) round(t, ra, rb, ra2, rb2);
     };
+#ifdef ONMF_TRACE_WG
+    const unsigned long long trace_t1 = wall_clock64();        // set-up done, nothing loaded yet
+#endif
     if (sure) pipeline(std::true_type{});
     else pipeline(std::false_type{});
+#ifdef ONMF_TRACE_WG
+    const unsigned long long trace_t2 = wall_clock64();        // main loop done
+#endif
 
     // accumulator element e of lane l: row (e&3) + 8*(e>>2) + 4*(l>>5), column l&31
     const bool direct = (p.splits == 1);
@@ -399,7 +413,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmParams p) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             const int col = n0 + wn + 32 * j + l31;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -424,7 +438,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmParams p) {
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
             g_wg_trace[4 * slot + 0] = trace_t0;
             g_wg_trace[4 * slot + 1] = wall_clock64();
-            g_wg_trace[4 * slot + 2] = ((unsigned long long)xcc << 32) | hw;
+            // (bits 36..49 / 50..63: set-up and main loop done, in units of 4 clock ticks after the start)
+            const unsigned long long d1 = ((trace_t1 - trace_t0) >> 2) & 0x3fffull, d2 = ((trace_t2 - trace_t0) >> 2) & 0x3fffull;
+            g_wg_trace[4 * slot + 2] = ((unsigned long long)(xcc & 15u) << 32) | hw | (d1 << 36) | (d2 << 50);
             g_wg_trace[4 * slot + 3] = ((unsigned long long)gridDim.x << 32) | ((unsigned long long)gridDim.z << 20) |
                                        (A_KM ? 2u : 0u) | (B_KN ? 1u : 0u);
         }
@@ -472,14 +488,22 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
-template <bool A_KM, bool B_KN>
-int run(onmf_ctx* c, const GemmParams& p, dim3 grid, hipStream_t s) {
-    constexpr size_t bytes = sizeof(float) * 4 * TILE_ELEMS;
+template <bool A_KM, bool B_KN, int BMT>
+int run_bm(onmf_ctx* c, const GemmParams& p, dim3 grid, hipStream_t s) {
+    constexpr size_t bytes = sizeof(float) * (2 * BMT * BK + 2 * TILE_ELEMS);
     static LdsLimit lim;
-    ONMF_TRY(onmf_raise_lds_limit(c, lim, (const void*)gemm_f32_kernel<A_KM, B_KN>, bytes));
-    hipLaunchKernelGGL((gemm_f32_kernel<A_KM, B_KN>), grid, dim3(NTHREADS), bytes, s, p);
+    ONMF_TRY(onmf_raise_lds_limit(c, lim, (const void*)gemm_f32_kernel<A_KM, B_KN, BMT>, bytes));
+    hipLaunchKernelGGL((gemm_f32_kernel<A_KM, B_KN, BMT>), grid, dim3(NTHREADS), bytes, s, p);
     HIP_TRY(c, hipGetLastError());
     return ONMF_OK;
+}
+
+// rows of the output tile for an output of M rows
+inline int tile_rows(int M) { return M <= 64 ? 64 : 128; }
+
+template <bool A_KM, bool B_KN>
+int run(onmf_ctx* c, const GemmParams& p, dim3 grid, hipStream_t s) {
+    return tile_rows(p.M) == 64 ? run_bm<A_KM, B_KN, 64>(c, p, grid, s) : run_bm<A_KM, B_KN, 128>(c, p, grid, s);
 }
 
 }  // namespace
@@ -497,7 +521,8 @@ int launch_gemm(onmf_ctx* c, bool a_km, bool b_kn, int M, int N, int K, const fl
     p.vecA = (((uintptr_t)A & 15) == 0 && (lda & 3) == 0) ? 1 : 0;
     p.vecB = (((uintptr_t)B & 15) == 0 && (ldb & 3) == 0) ? 1 : 0;
     p.B2 = nullptr; p.ldb2 = 0; p.n1 = 0; p.n1p = 0; p.vecB2 = 0;
-    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    const int bm = tile_rows(M);
+    const int tiles_m = (M + bm - 1) / bm, tiles_n = (N + BN - 1) / BN;
     p.tiles_n = tiles_n;
     const int tiles = tiles_m * tiles_n;
     const int ktiles = (K + BK - 1) / BK;
@@ -562,7 +587,8 @@ int launch_gemm_pair(onmf_ctx* c, bool a_km, bool b_kn, int M, int K, const floa
                                 beta1, Cin1, C1, ldc1, s, slab);
     const int N1p = (N1 + BN - 1) / BN * BN;          // the second product's tiles start on a tile boundary
     const int N = N1p + N2;
-    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    const int bm = tile_rows(M);
+    const int tiles_m = (M + bm - 1) / bm, tiles_n = (N + BN - 1) / BN;
     const int tiles = tiles_m * tiles_n;
     const int ktiles = (K + BK - 1) / BK;
     int splits = (tiles > 4 && tiles < 256 && ktiles >= 4) ? std::min(SPLIT_WG_BUDGET / tiles, ktiles / 2) : 1;

@@ -93,6 +93,10 @@ for t_first, tag, recs in launches[first:]:
     print("\nproduct %s%s grid %d x %d: %8.1f -> %8.1f (%6.1f us); workgroup run time min %.1f median %.1f max %.1f"
           % ("T" if tag & 2 else "N", "T" if tag & 1 else "N", gx, gz, st.min(), en.max(), en.max() - st.min(),
              du.min(), np.median(du), du.max()))
+    d1 = np.array([((int(q[2]) >> 36) & 0x3fff) * 4 * TICK for q in recs])
+    d2 = np.array([((int(q[2]) >> 50) & 0x3fff) * 4 * TICK for q in recs])
+    print("  inside a workgroup (median us): set-up %.2f, loads + main loop %.2f, results out %.2f"
+          % (np.median(d1), np.median(d2 - d1), np.median(du - d2)))
     rel = st - st.min()
     hist = np.histogram(rel, bins=np.arange(0, rel.max() + 20, 20))[0]
     print("  starts per 20 us: " + " ".join(str(v) for v in hist))
