@@ -389,6 +389,10 @@ double onmf_host_lambda_max(const float* S_host, int n);
  *   ONMF_OPT_DEFER_VERDICT != 0: onmf_step calls that return no host scalars do not wait for the stopping test's
  *                          verdicts; see onmf_settle.  0 (default): every call's outputs are final when it returns
  *                          (in stream order).
+ *   ONMF_OPT_GEMM_TAIL     experiment, off (0) by default: 100 * p + n computes the last p per cent of the tiles of
+ *                          the big W^T X launch in n pieces along the contraction, summed by a small kernel
+ *                          (measured: no gain at any setting; results differ from the default in the last bits
+ *                          of those columns of W^T X).
  *   ONMF_OPT_SPIN_LIMIT_MS bound, in milliseconds, of the waits of workgroups for each other - a
  *                          one-launch solve's, and the dictionary pass's for d > 1024 (default 2000;
  *                          -1: give up at the first look if what is waited for is not there yet; -2: give
@@ -411,6 +415,7 @@ double onmf_host_lambda_max(const float* S_host, int n);
 #define ONMF_OPT_DEVICE_RESOLVE 9
 #define ONMF_OPT_LARS_SLOTS 10
 #define ONMF_OPT_DEFER_VERDICT 11
+#define ONMF_OPT_GEMM_TAIL 12
 int onmf_set_option(onmf_ctx* ctx, int key, int value);
 /*
  * Event counters since onmf_create (no counterpart in the reference):

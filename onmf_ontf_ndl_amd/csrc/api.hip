@@ -201,6 +201,7 @@ int onmf_set_option(onmf_ctx* c, int key, int value) {
         case ONMF_OPT_DEVICE_RESOLVE: c->device_resolve = value; return ONMF_OK;
         case ONMF_OPT_LARS_SLOTS: c->lars_slots = value < 0 ? 0 : value; return ONMF_OK;
         case ONMF_OPT_DEFER_VERDICT: c->defer_verdict = value; return ONMF_OK;
+        case ONMF_OPT_GEMM_TAIL: c->gemm_tail = value < 0 ? 0 : value; return ONMF_OK;
         case ONMF_OPT_SPIN_LIMIT_MS:
             c->spin_limit = value == -2 ? SPIN_FORCE_TIMEOUT
                                         : value < 0 ? -1LL : (long long)value * 100000LL;      // 100 MHz ticks
@@ -468,7 +469,8 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
             cm_rc = launch_gemm_pair(c, true, true, r, d, W, r, X, ldx, b, W, r, r, 1.f, 0.f, nullptr, Cm, b, 0.f, nullptr,
                                      Gm, r, s, nullptr);
         else
-            cm_rc = launch_gemm(c, true, true, r, b - tail_cols, d, W, r, X, ldx, 1.f, 0.f, nullptr, Cm, b, s);
+            cm_rc = launch_gemm(c, true, true, r, b - tail_cols, d, W, r, X, ldx, 1.f, 0.f, nullptr, Cm, b, s, nullptr,
+                                c->gemm_tail);
     }
     if (behind_products && cm_rc == ONMF_OK && prep_rc == ONMF_OK) cm_rc = (*behind_products)();
     if (ps != s) {                       // always rejoin, also on an error path

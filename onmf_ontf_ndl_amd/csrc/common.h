@@ -77,6 +77,7 @@ struct onmf_ctx {
     hipEvent_t ev_prep_fork = nullptr, ev_prep_join = nullptr;
     DevBuf slab_prep;               // split-K slabs of products issued on the preparation stream
     int overlap_dict = 1;
+    int gemm_tail = 0;          // finer grain at the end of the big W^T X launch: 100 * percent of tiles + pieces (0: off)
     int screen_stop = 1;
     int screen_r = -1;              // r of the probes currently held in `screen`
     bool screen_refresh_due = true; // the next screened solve runs a probe power step
@@ -182,7 +183,7 @@ inline int onmf_raise_lds_limit(onmf_ctx* c, LdsLimit& lim, const void* kernel, 
 // b_kn: B(k,n)=B[k*ldb+n] else B[n*ldb+k].  Cin may be null when beta == 0; Cin may alias C.
 int launch_gemm(onmf_ctx* c, bool a_km, bool b_kn, int M, int N, int K, const float* A, int lda,
                 const float* B, int ldb, float alpha, float beta, const float* Cin, float* C,
-                int ldc, hipStream_t s, DevBuf* slab = nullptr);
+                int ldc, hipStream_t s, DevBuf* slab = nullptr, int tail_spec = 0);
 
 // Two products that share the left operand, A B1^T and A B2^T (all operands contraction-fast), in one
 // launch where the shapes allow; see gemm.hip.

@@ -57,6 +57,11 @@ struct GemmParams {
     // dropped), the columns from n1p on with B2; N = n1p + (columns of the second product); n1 == 0: none
     const float* B2;
     int ldb2, n1, n1p, vecB2;
+    // finer grain at the end of an unsplit launch: workgroups from tail_first on compute the tiles from
+    // tail_first on in tail_splits pieces of tail_k contraction steps each, into tile-shaped slabs
+    // (tail_slab[(tile - tail_first) * tail_splits + piece][128][128]) that tail_reduce_kernel sums; -1: none
+    int tail_first, tail_splits, tail_k;
+    float* tail_slab;
 };
 
 // Which element of a BK x ROWS operand tile (ROWS = 128 or 64 rows of the output it feeds) thread t handles
@@ -259,12 +264,20 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmParams p) {
         }
     }
 #else
-    const int tile = blockIdx.x, z = blockIdx.z;
+    int tile = blockIdx.x;
+    const int z = blockIdx.z;
 #endif
+    int kbeg = z * p.k_per_split;
+    int kend = min(p.K, kbeg + p.k_per_split);
+    int tail_piece = -1;                         // index of this workgroup's slab when it computes a piece of a tail tile
+    if (p.tail_first >= 0 && tile >= p.tail_first) {
+        tail_piece = tile - p.tail_first;
+        tile = p.tail_first + tail_piece / p.tail_splits;
+        kbeg = (tail_piece % p.tail_splits) * p.tail_k;
+        kend = min(p.K, kbeg + p.tail_k);
+    }
     const int m0 = (tile / p.tiles_n) * BMT;
     const int n0 = (tile % p.tiles_n) * BN;
-    const int kbeg = z * p.k_per_split;
-    const int kend = min(p.K, kbeg + p.k_per_split);
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -407,6 +420,18 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(GemmParams p) {
 #endif
 
     // accumulator element e of lane l: row (e&3) + 8*(e>>2) + 4*(l>>5), column l&31
+    if (tail_piece >= 0) {
+        // a piece of a tail tile: the bare sums, tile-shaped
+        float* slab = p.tail_slab + (size_t)tail_piece * (BMT * BN);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    slab[(wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * lhi) * BN + wn + 32 * j + l31] = acc[i][j][e];
+        return;
+    }
     const bool direct = (p.splits == 1);
     float* out = direct ? p.C : p.slab + (size_t)z * p.M * p.N;
     const int ldo = direct ? p.ldc : p.N;
@@ -488,6 +513,34 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
+// Sum of the pieces of the tail tiles (fixed order) into C: one workgroup per tile, four outputs per thread
+// and trip.
+__global__ __launch_bounds__(256) void tail_reduce_kernel(const float* __restrict__ slab, int tail_first, int tail_tiles,
+                                                           int splits, int tiles_n, int bmt, int M, int N, float alpha,
+                                                           float* __restrict__ C, int ldc) {
+    const int tile = tail_first + blockIdx.x;
+    const int m0 = (tile / tiles_n) * bmt, n0 = (tile % tiles_n) * BN;
+    const float* base = slab + (size_t)blockIdx.x * splits * (bmt * BN);
+    for (int e = threadIdx.x * 4; e < bmt * BN; e += 256 * 4) {
+        float4 sum = *reinterpret_cast<const float4*>(base + e);
+        for (int z = 1; z < splits; ++z) {
+            const float4 v = *reinterpret_cast<const float4*>(base + (size_t)z * (bmt * BN) + e);
+            sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+        }
+        const int row = m0 + e / BN, col = n0 + e % BN;
+        if (row >= M) continue;
+        float* dst = C + (size_t)row * ldc + col;
+        if (col + 3 < N && ((ldc & 3) == 0) && (((uintptr_t)C & 15) == 0)) {
+            *reinterpret_cast<float4*>(dst) = make_float4(alpha * sum.x, alpha * sum.y, alpha * sum.z, alpha * sum.w);
+        } else {
+            if (col + 0 < N) dst[0] = alpha * sum.x;
+            if (col + 1 < N) dst[1] = alpha * sum.y;
+            if (col + 2 < N) dst[2] = alpha * sum.z;
+            if (col + 3 < N) dst[3] = alpha * sum.w;
+        }
+    }
+}
+
 template <bool A_KM, bool B_KN, int BMT>
 int run_bm(onmf_ctx* c, const GemmParams& p, dim3 grid, hipStream_t s) {
     constexpr size_t bytes = sizeof(float) * (2 * BMT * BK + 2 * TILE_ELEMS);
@@ -510,7 +563,7 @@ int run(onmf_ctx* c, const GemmParams& p, dim3 grid, hipStream_t s) {
 
 int launch_gemm(onmf_ctx* c, bool a_km, bool b_kn, int M, int N, int K, const float* A, int lda,
                 const float* B, int ldb, float alpha, float beta, const float* Cin, float* C,
-                int ldc, hipStream_t s, DevBuf* slab) {
+                int ldc, hipStream_t s, DevBuf* slab, int tail_spec) {
     if (!slab) slab = &c->slab;
     if (M <= 0 || N <= 0 || K < 0) return onmf_fail(c, ONMF_ERR_ARG, "gemm: bad shape %dx%dx%d", M, N, K);
     if (beta != 0.f && Cin == nullptr) return onmf_fail(c, ONMF_ERR_ARG, "gemm: beta without Cin");
@@ -521,6 +574,7 @@ int launch_gemm(onmf_ctx* c, bool a_km, bool b_kn, int M, int N, int K, const fl
     p.vecA = (((uintptr_t)A & 15) == 0 && (lda & 3) == 0) ? 1 : 0;
     p.vecB = (((uintptr_t)B & 15) == 0 && (ldb & 3) == 0) ? 1 : 0;
     p.B2 = nullptr; p.ldb2 = 0; p.n1 = 0; p.n1p = 0; p.vecB2 = 0;
+    p.tail_first = -1; p.tail_splits = 0; p.tail_k = 0; p.tail_slab = nullptr;
     const int bm = tile_rows(M);
     const int tiles_m = (M + bm - 1) / bm, tiles_n = (N + BN - 1) / BN;
     p.tiles_n = tiles_n;
@@ -548,12 +602,35 @@ int launch_gemm(onmf_ctx* c, bool a_km, bool b_kn, int M, int N, int K, const fl
         p.slab = (float*)slab->p;
     }
     dim3 grid(tiles, 1, splits);
+    // An unsplit product of several rounds of workgroups ends with whichever CU drew one workgroup more than
+    // the others - a whole tile's time when other kernels hold places.  tail_spec = 100 * percent + pieces:
+    // the last `percent` of the tiles are computed in `pieces` pieces along the contraction (workgroups
+    // that short fill the last round evenly) and summed by a small kernel behind the launch.
+    int tail_tiles = 0;
+    if (tail_spec > 0 && splits == 1 && beta == 0.f && tiles >= 512) {
+        const int pieces = tail_spec % 100, percent = tail_spec / 100;
+        if (pieces >= 2 && percent >= 1 && percent <= 90 && ktiles >= 4 * pieces) {
+            tail_tiles = tiles * percent / 100;
+            const int kt = (ktiles + pieces - 1) / pieces;
+            p.tail_first = tiles - tail_tiles;
+            p.tail_splits = (ktiles + kt - 1) / kt;
+            p.tail_k = kt * BK;
+            ONMF_TRY(onmf_reserve(c, *slab, (size_t)tail_tiles * p.tail_splits * bm * BN * sizeof(float), "tail slabs"));
+            p.tail_slab = (float*)slab->p;
+            grid.x = p.tail_first + tail_tiles * p.tail_splits;
+        }
+    }
     int rc;
     if (a_km && b_kn) rc = run<true, true>(c, p, grid, s);
     else if (a_km && !b_kn) rc = run<true, false>(c, p, grid, s);
     else if (!a_km && b_kn) rc = run<false, true>(c, p, grid, s);
     else rc = run<false, false>(c, p, grid, s);
     if (rc != ONMF_OK) return rc;
+    if (tail_tiles > 0) {
+        hipLaunchKernelGGL(tail_reduce_kernel, dim3(tail_tiles), dim3(256), 0, s, p.tail_slab, p.tail_first, tail_tiles,
+                           p.tail_splits, tiles_n, bm, M, N, alpha, C, ldc);
+        HIP_TRY(c, hipGetLastError());
+    }
     if (splits > 1) {
         const size_t mn = (size_t)M * N;
         int blocks = (int)((mn + 63) / 64);
@@ -608,6 +685,7 @@ int launch_gemm_pair(onmf_ctx* c, bool a_km, bool b_kn, int M, int K, const floa
     p.B2 = B2; p.ldb2 = ldb2; p.n1 = N1; p.n1p = N1p;
     p.vecB2 = (((uintptr_t)B2 & 15) == 0 && (ldb2 & 3) == 0) ? 1 : 0;
     p.tiles_n = tiles_n;
+    p.tail_first = -1; p.tail_splits = 0; p.tail_k = 0; p.tail_slab = nullptr;
     const int kt_per = (ktiles + splits - 1) / splits;
     splits = (ktiles + kt_per - 1) / kt_per;
     p.k_per_split = kt_per * BK;
