@@ -105,6 +105,14 @@ __global__ __launch_bounds__(64 * WPG) void sweep_tile_kernel(
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NBLK = HALF ? NB * (NB + 1) / 2 : NB * NB;
     constexpr int NT = 64 * WPG;           // threads per workgroup
+    // Two tiles per wave: the in-block update runs on both at once.  A v_permlane16_swap of the two tiles'
+    // registers leaves lane group g with 8 consecutive rows (8 (g >> 1) .. + 7) of ONE column of tile g & 1;
+    // the rows are then updated in order inside the lane, first half of the block in the lower half of the
+    // wave, then the second half in the upper one - every instruction serves both tiles and nothing crosses
+    // lanes inside a half; between the halves the first half's deltas are pushed into the second half's
+    // gradients by two MFMAs per tile.  Same operations on every row in the same order as the
+    // quad-by-quad form: bit-identical codes.
+    constexpr bool PAIR = (CT == 2) && !EACH;
     constexpr int WAVES = WPG;
     float* Gs = lds;                       // NBLK swizzled 16x16 blocks of Gm
     // The current sweep's step sizes, negated, as four tables of 16*NB: table Q holds the entries of the
@@ -303,8 +311,16 @@ __global__ __launch_bounds__(64 * WPG) void sweep_tile_kernel(
                     const float gjj = gdiag[j];
                     st = exact_cd ? (gjj > 0.f ? 1.0f / gjj : 0.f) : rdamp / (gjj + 1.0f);
                 }
+                if (PAIR) {
+                    // table [phase][half of the wave][block][8]: in phase ph the lanes of half hh hold rows
+                    // 8 hh .. 8 hh + 7 of the block and move only when hh == ph
+                    const int Kb = j >> 4, ph = (j >> 3) & 1, i8 = j & 7;
+                    steps[((ph * 2 + ph) * NB + Kb) * 8 + i8] = -st;
+                    steps[((ph * 2 + (1 - ph)) * NB + Kb) * 8 + i8] = 0.f;
+                } else {
 #pragma unroll
-                for (int Q = 0; Q < 4; ++Q) steps[Q * 16 * NB + j] = (((j >> 2) & 3) == Q) ? -st : 0.f;
+                    for (int Q = 0; Q < 4; ++Q) steps[Q * 16 * NB + j] = (((j >> 2) & 3) == Q) ? -st : 0.f;
+                }
             }
             if (PROBE) {
                 if (tid < 16) p2wg[tid] = 0.f;
@@ -448,6 +464,86 @@ __global__ __launch_bounds__(64 * WPG) void sweep_tile_kernel(
                 }
             }
 
+            if constexpr (PAIR) {
+                float a8[8], h8[8], d8[8];
+    #pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const auto sa = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[0][t]), __float_as_uint(acc[CT - 1][t]), false, false);
+                    a8[t] = __uint_as_float(sa[0]);
+                    a8[4 + t] = __uint_as_float(sa[1]);
+                    const auto sh = __builtin_amdgcn_permlane16_swap(__float_as_uint(h[0][K][t]), __float_as_uint(h[CT - 1][K][t]), false, false);
+                    h8[t] = __uint_as_float(sh[0]);
+                    h8[4 + t] = __uint_as_float(sh[1]);
+                }
+                const int hh = g >> 1;
+                // the diagonal block's address in a register of its own (made opaque): the entries read below,
+                // the same in every lane, are then immediate offsets from it
+                unsigned gd_addr = (unsigned)(size_t)(lds_cfloat*)(Gs + blk_index<NB, HALF>(K, K) * 256);
+                asm volatile("" : "+v"(gd_addr));
+                lds_cfloat* Gd = (lds_cfloat*)(size_t)gd_addr;
+                typedef __attribute__((address_space(3))) const f32x4 lds_cf32x4;
+                auto half_update = [&](auto ph_c) {
+                    constexpr int ph = decltype(ph_c)::value;
+                    const float4 n0 = *reinterpret_cast<const float4*>(steps + ((ph * 2) * NB + K) * 8 + hh * (NB * 8));
+                    const float4 n1 = *reinterpret_cast<const float4*>(steps + ((ph * 2) * NB + K) * 8 + hh * (NB * 8) + 4);
+                    const float nst[8] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w};
+                    const float floor_p = (hh == ph) ? 0.f : -__builtin_inff();
+    #pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        // row 8 ph + j of the block; its entries of Gm towards the later rows of this half
+                        // (Gm is symmetric: column entries are read as the row's), the same in every lane
+                        const int rj = 8 * ph + j;
+                        float grow[16];
+    #pragma unroll
+                        for (int q4 = (rj + 1) >> 2; q4 < 2 * ph + 2; ++q4) {
+                            const f32x4 v = *reinterpret_cast<lds_cf32x4*>(Gd + rj * 16 + 4 * (q4 ^ swz(rj)));
+                            grow[4 * q4 + 0] = v[0]; grow[4 * q4 + 1] = v[1]; grow[4 * q4 + 2] = v[2]; grow[4 * q4 + 3] = v[3];
+                        }
+                        const float hold = h8[j];
+                        const float hnew = fmaxf(fmaf(a8[j], nst[j], hold), floor_p);
+                        const float dl = hnew - hold;
+                        h8[j] = hnew;
+                        d8[j] = dl;
+    #pragma unroll
+                        for (int i = j + 1; i < 8; ++i) a8[i] = fmaf(grow[8 * ph + i], dl, a8[i]);
+                    }
+                };
+                half_update(std::integral_constant<int, 0>{});
+                // The first half's deltas into the second half's gradients: two MFMAs per tile on the
+                // accumulators in their own layout (rows 8 .. 15 of them are untouched so far),
+                // acc[16 rows][col] += G[rows][4q .. 4q+3] . delta[4q .. 4q+3][col].  The B operand wants delta
+                // row 4q + g in lane group g: the deltas sit in lane group 0 (first tile) and 1 (second tile)
+                // as registers 4q .. 4q+3, so a 4 x 4 exchange of register index against lane group leaves
+                // the first tile's operand in register 0 and the second tile's in register 1.
+    #pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    float x0 = d8[4 * q], x1 = d8[4 * q + 1], x2 = d8[4 * q + 2], x3 = d8[4 * q + 3];
+                    xpose_reg_group(x0, x1, x2, x3);
+                    const float a_push = Gs[blk_index<NB, HALF>(K, K) * 256 + c * 16 + 4 * (q ^ sw_c) + g];
+                    f32x4 av0 = {acc[0][0], acc[0][1], acc[0][2], acc[0][3]};
+                    f32x4 av1 = {acc[CT - 1][0], acc[CT - 1][1], acc[CT - 1][2], acc[CT - 1][3]};
+                    av0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_push, x0, av0, 0, 0, 0);
+                    av1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_push, x1, av1, 0, 0, 0);
+    #pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        acc[0][t] = av0[t];
+                        acc[CT - 1][t] = av1[t];
+                    }
+                }
+    #pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const auto sa = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[0][t]), __float_as_uint(acc[CT - 1][t]), false, false);
+                    a8[t] = __uint_as_float(sa[0]);
+                    a8[4 + t] = __uint_as_float(sa[1]);
+                }
+                half_update(std::integral_constant<int, 1>{});
+    #pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const auto sh = __builtin_amdgcn_permlane16_swap(__float_as_uint(h8[t]), __float_as_uint(h8[4 + t]), false, false);
+                    h[0][K][t] = __uint_as_float(sh[0]);
+                    h[CT - 1][K][t] = __uint_as_float(sh[1]);
+                }
+            } else {
     #pragma unroll
             for (int Q = 0; Q < 4; ++Q) {
                 const bool own = (g == Q);
@@ -506,6 +602,7 @@ __global__ __launch_bounds__(64 * WPG) void sweep_tile_kernel(
                     }
                 }
             }
+            }   // (quad-by-quad form)
     #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
     #pragma unroll
