@@ -68,6 +68,25 @@ def test_matrix_products_all_layouts(eng, shape):
     assert relerr(host(B2), H64 @ X64.T) < 2e-6
 
 
+@pytest.mark.parametrize("shape", [(49, 100, 1000), (64, 16, 129), (33, 7, 4100), (147, 100, 333), (64, 64, 8192),
+                                   (12, 250, 640), (200, 60, 70)])
+def test_products_with_narrow_outputs_and_operands(eng, shape):
+    """Outputs of at most 64 rows take the product kernel's 64-row tile, operands narrower than a tile its
+    range-checked loads: W H (rows of W fast, rows of H slow), H H^T | H X^T with few atoms, against float64."""
+    d, r, b = shape
+    rs = np.random.RandomState(7 * d + r + b)
+    W = (rs.rand(d, r) - 0.4).astype(np.float32)
+    H = rs.rand(r, b).astype(np.float32)
+    X = (rs.rand(d, b) - 0.2).astype(np.float32)
+    R = eng.patch_product(eng.dev(W), eng.dev(H))
+    assert relerr(host(R), W.astype(np.float64) @ H.astype(np.float64)) < 2e-6
+    A1, B1, _ = eng.aggregate(eng.dev(X), eng.dev(H), 1.0, None, None)
+    H64, X64 = H.astype(np.float64), X.astype(np.float64)
+    assert relerr(host(A1), H64 @ H64.T) < 2e-6
+    assert relerr(host(B1), H64 @ X64.T) < 2e-6
+    assert np.array_equal(host(A1), host(A1).T)                      # exactly symmetric whatever the tile
+
+
 def test_fill_uniform_statistics(eng):
     u = host(eng.rand(256, 4099, seed=7))
     assert u.min() >= 0.0 and u.max() < 1.0
