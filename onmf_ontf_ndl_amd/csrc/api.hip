@@ -1238,8 +1238,7 @@ int onmf_sparse_code_lars(onmf_ctx* c, int d, int r, int b, const float* X, int 
     double* Gd = (double*)c->gram64.p;
     double* Cd = (double*)c->cm64.p;
     // the Gram matrix and the correlations the library is handed (_dict_learning.py: gram = W^T W, cov = W^T X)
-    ONMF_TRY(launch_prod_f64(c, r, r, d, W, r, W, r, Gd, r, s));
-    ONMF_TRY(launch_prod_f64(c, r, b, d, W, r, X, ldx, Cd, b, s));
+    ONMF_TRY(launch_prod_f64_pair(c, r, d, W, r, X, ldx, b, Cd, b, W, r, r, Gd, r, s));     // [W^T X | W^T W]
     return launch_lars_pos(c, r, b, Gd, Cd, b, alpha, (double)d, max_iter, H, b, info, s);
 }
 
@@ -1274,8 +1273,7 @@ int onmf_ntf_step(onmf_ctx* c, int d, int r, int b, const float* X, int ldx, con
         HIP_TRY(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
     }
     int rc_dict = beside ? launch_dict_pass(c, d, r, W_in, A_in, B_in, W_out, c->side, 0) : ONMF_OK;
-    int rc = launch_prod_f64(c, r, r, d, W_in, r, W_in, r, Gd, r, s);
-    if (rc == ONMF_OK) rc = launch_prod_f64(c, r, b, d, W_in, r, X, ldx, Cd, b, s);
+    int rc = launch_prod_f64_pair(c, r, d, W_in, r, X, ldx, b, Cd, b, W_in, r, r, Gd, r, s);   // [W^T X | W^T W]
     if (rc == ONMF_OK) rc = launch_lars_pos(c, r, b, Gd, Cd, b, alpha, (double)d, max_iter, H, b, info, s);
     if (rc == ONMF_OK && !beside) rc = launch_dict_pass(c, d, r, W_in, A_in, B_in, W_out, s, 0);
     if (rc == ONMF_OK) rc = aggregate_impl(c, d, r, b, X, ldx, H, w, A_in, B_in, nullptr, A_out, B_out, nullptr, s);

@@ -476,6 +476,9 @@ const float* dict_staged_wt(const onmf_ctx* c, int d, int r);
 // Out (M x N, double) = A^T B for float operands stored contraction-major (A[k*lda + m], B[k*ldb + n])
 int launch_prod_f64(onmf_ctx* c, int M, int N, int K, const float* A, int lda, const float* B, int ldb, double* Out,
                     int ldo, hipStream_t s);
+int launch_prod_f64_pair(onmf_ctx* c, int M, int K, const float* A, int lda, const float* B1, int ldb1, int N1,
+                         double* Out1, int ldo1, const float* B2, int ldb2, int N2, double* Out2, int ldo2,
+                         hipStream_t s);
 // scikit-learn's positive LARS-lasso path per column (lars.hip): G (r x r), Cd (r x b, leading dimension
 // ldc) in double; H (r x b, leading dimension ldh) out; info: device int[4*b] or null
 int launch_lars_pos(onmf_ctx* c, int r, int b, const double* G, const double* Cd, int ldc, double alpha,

@@ -39,27 +39,53 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 // ---------------------------------------------------------------------------------------------
 constexpr int PT = 64, PK = 64, PPITCH = 80;
 
+// NBL: 16-column blocks per wave (output tile 64 x 16 NBL).  Two instead of four doubles the number of
+// workgroups: at the shapes of this path (a hundred atoms, a few thousand columns) the grid is otherwise one
+// four-wave workgroup per CU, and one wave per SIMD leaves every LDS-read -> convert -> MFMA chain exposed.
+template <int NBL>
+// A second product with the same left operand rides in the same launch: the column tiles from tile n1_tiles
+// on contract with B2 (N2 columns) and go to Out2.
 __global__ __launch_bounds__(256) void prod_f64_kernel(int M, int N, int K, const float* __restrict__ A, int lda,
                                                        const float* __restrict__ B, int ldb,
-                                                       double* __restrict__ Out, int ldo) {
-    __shared__ float sa[PK * PPITCH], sb[PK * PPITCH];
+                                                       double* __restrict__ Out, int ldo, int n1_tiles,
+                                                       const float* __restrict__ B2, int ldb2, int N2,
+                                                       double* __restrict__ Out2, int ldo2) {
+    constexpr int PTN = 16 * NBL;                     // columns of the output tile
+    constexpr int BPITCH = PTN + 16;
+    __shared__ float sa[PK * PPITCH], sb[PK * BPITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.y * PT, n0 = blockIdx.x * PT;
-    f64x4 acc[4];
+    const int m0 = blockIdx.y * PT;
+    int n0 = blockIdx.x * PTN;
+    if ((int)blockIdx.x >= n1_tiles) {                // (workgroup-uniform) the second product's tiles
+        n0 = ((int)blockIdx.x - n1_tiles) * PTN;
+        B = B2; ldb = ldb2; N = N2; Out = Out2; ldo = ldo2;
+    }
+    f64x4 acc[NBL];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i] = f64x4{0.0, 0.0, 0.0, 0.0};
-    // a tile is PK contraction steps x 64 columns per operand: thread t fetches rows (t >> 4) + 16 j, four
-    // consecutive columns each - the next tile's 2 x 16 loads are in flight while this one is multiplied
+    for (int i = 0; i < NBL; ++i) acc[i] = f64x4{0.0, 0.0, 0.0, 0.0};
+    // a tile is PK contraction steps x 64 (A) or PTN (B) columns: thread t fetches four consecutive columns of
+    // rows (t >> 4) + 16 j of A and of rows (t / (PTN / 4)) + (1024 / PTN) j of B - the next tile's loads are
+    // in flight while this one is multiplied
     const int lk = tid >> 4, lx = (tid & 15) * 4;
-    float ra[PK / 16][4], rb[PK / 16][4];
+    constexpr int BROWS = 1024 / PTN;                 // rows of B one pass of the workgroup covers
+    const int bk = tid / (PTN / 4), bx = (tid % (PTN / 4)) * 4;
+    float ra[PK / 16][4], rb[PK / BROWS][4];
     auto fetch = [&](int k0) {
 #pragma unroll
         for (int j = 0; j < PK / 16; ++j) {
             const int k = k0 + lk + 16 * j;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int m = m0 + lx + i, n = n0 + lx + i;
+                const int m = m0 + lx + i;
                 ra[j][i] = (k < K && m < M) ? A[(size_t)k * lda + m] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < PK / BROWS; ++j) {
+            const int k = k0 + bk + BROWS * j;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int n = n0 + bx + i;
                 rb[j][i] = (k < K && n < N) ? B[(size_t)k * ldb + n] : 0.f;
             }
         }
@@ -70,26 +96,27 @@ __global__ __launch_bounds__(256) void prod_f64_kernel(int M, int N, int K, cons
 #pragma unroll
         for (int j = 0; j < PK / 16; ++j)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                sa[(lk + 16 * j) * PPITCH + lx + i] = ra[j][i];
-                sb[(lk + 16 * j) * PPITCH + lx + i] = rb[j][i];
-            }
+            for (int i = 0; i < 4; ++i) sa[(lk + 16 * j) * PPITCH + lx + i] = ra[j][i];
+#pragma unroll
+        for (int j = 0; j < PK / BROWS; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sb[(bk + BROWS * j) * BPITCH + bx + i] = rb[j][i];
         __syncthreads();
         if (k0 + PK < K) fetch(k0 + PK);
 #pragma unroll
         for (int kk = 0; kk < PK / 4; ++kk) {
-            const int krow = (kk * 4 + (lane >> 4)) * PPITCH;
-            const double av = (double)sa[krow + wave * 16 + (lane & 15)];
+            const int krow = kk * 4 + (lane >> 4);
+            const double av = (double)sa[krow * PPITCH + wave * 16 + (lane & 15)];
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb) {
-                const double bv = (double)sb[krow + nb * 16 + (lane & 15)];
+            for (int nb = 0; nb < NBL; ++nb) {
+                const double bv = (double)sb[krow * BPITCH + nb * 16 + (lane & 15)];
                 acc[nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[nb], 0, 0, 0);
             }
         }
     }
     // result register i of a lane: row (lane >> 4) + 4 i, column lane & 15 of the 16 x 16 block
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) {
+    for (int nb = 0; nb < NBL; ++nb) {
         const int n = n0 + nb * 16 + (lane & 15);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -724,12 +751,30 @@ int launch_lars_q(onmf_ctx* c, const LarsArgs& a0, hipStream_t s) {
 
 }  // namespace
 
-int launch_prod_f64(onmf_ctx* c, int M, int N, int K, const float* A, int lda, const float* B, int ldb, double* Out,
-                    int ldo, hipStream_t s) {
-    dim3 grid((N + PT - 1) / PT, (M + PT - 1) / PT);
-    hipLaunchKernelGGL(prod_f64_kernel, grid, dim3(256), 0, s, M, N, K, A, lda, B, ldb, Out, ldo);
+// Out1 = A^T B1 (M x N1) and, when B2 is given, Out2 = A^T B2 (M x N2) in the same launch (A [k][m], B [k][n])
+int launch_prod_f64_pair(onmf_ctx* c, int M, int K, const float* A, int lda, const float* B1, int ldb1, int N1,
+                         double* Out1, int ldo1, const float* B2, int ldb2, int N2, double* Out2, int ldo2,
+                         hipStream_t s) {
+    const int tiles_m = (M + PT - 1) / PT;
+    if (!B2) N2 = 0;
+    if ((long long)tiles_m * ((N1 + 63) / 64 + (N2 + 63) / 64) >= 1024) {   // several workgroups per CU as it is
+        const int t1 = (N1 + 63) / 64;
+        dim3 grid(t1 + (N2 + 63) / 64, tiles_m);
+        hipLaunchKernelGGL(prod_f64_kernel<4>, grid, dim3(256), 0, s, M, N1, K, A, lda, B1, ldb1, Out1, ldo1, t1, B2, ldb2,
+                           N2, Out2, ldo2);
+    } else {
+        const int t1 = (N1 + 31) / 32;
+        dim3 grid(t1 + (N2 + 31) / 32, tiles_m);
+        hipLaunchKernelGGL(prod_f64_kernel<2>, grid, dim3(256), 0, s, M, N1, K, A, lda, B1, ldb1, Out1, ldo1, t1, B2, ldb2,
+                           N2, Out2, ldo2);
+    }
     if (hipGetLastError() != hipSuccess) return onmf_fail(c, ONMF_ERR_HIP, "double-precision product: launch failed");
     return ONMF_OK;
+}
+
+int launch_prod_f64(onmf_ctx* c, int M, int N, int K, const float* A, int lda, const float* B, int ldb, double* Out,
+                    int ldo, hipStream_t s) {
+    return launch_prod_f64_pair(c, M, K, A, lda, B, ldb, N, Out, ldo, nullptr, 0, 0, nullptr, 0, s);
 }
 
 int launch_lars_pos(onmf_ctx* c, int r, int b, const double* G, const double* Cd, int ldc, double alpha,
