@@ -12,8 +12,8 @@ import sys
 CU = 256          # compute units of an MI355X
 PICK = {          # family -> (substring of the kernel name, passes that ran it)
     "sweep": ("sweep_tile_kernel", ["sweep_sq1", "sweep_sq2", "sweep_fetch", "sweep_write"]),
-    "gemm_tt": ("gemm_f32_kernel<true, true>", ["gemm_sq1", "gemm_sq2", "gemm_fetch", "gemm_write"]),
-    "gemm_ff": ("gemm_f32_kernel<false, false>", ["gemm_sq1", "gemm_sq2", "gemm_fetch", "gemm_write"]),
+    "gemm_tt": ("gemm_f32_kernel<true, true,", ["gemm_sq1", "gemm_sq2", "gemm_fetch", "gemm_write"]),
+    "gemm_ff": ("gemm_f32_kernel<false, false,", ["gemm_sq1", "gemm_sq2", "gemm_fetch", "gemm_write"]),
 }
 
 
