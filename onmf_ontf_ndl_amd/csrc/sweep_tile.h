@@ -464,6 +464,16 @@ __global__ __launch_bounds__(64 * WPG) void sweep_tile_kernel(
                 }
             }
 
+#if defined(ONMF_DIAG_SWEEP) && ONMF_DIAG_SWEEP == 1
+            // timing diagnostics only (wrong results): no in-block update at all
+            if constexpr (PAIR) {
+    #pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    h[0][K][t] = fmaxf(h[0][K][t] - 1e-4f * acc[0][t], 0.f);
+                    h[CT - 1][K][t] = fmaxf(h[CT - 1][K][t] - 1e-4f * acc[CT - 1][t], 0.f);
+                }
+            } else
+#endif
             if constexpr (PAIR) {
                 float a8[8], h8[8], d8[8];
     #pragma unroll
@@ -496,7 +506,12 @@ __global__ __launch_bounds__(64 * WPG) void sweep_tile_kernel(
                         float grow[16];
     #pragma unroll
                         for (int q4 = (rj + 1) >> 2; q4 < 2 * ph + 2; ++q4) {
+#if defined(ONMF_DIAG_SWEEP) && ONMF_DIAG_SWEEP == 2
+                            // timing diagnostics only (wrong results): the entries of Gm from registers
+                            const f32x4 v = {nst[0], nst[1], nst[2], nst[3]};
+#else
                             const f32x4 v = *reinterpret_cast<lds_cf32x4*>(Gd + rj * 16 + 4 * (q4 ^ swz(rj)));
+#endif
                             grow[4 * q4 + 0] = v[0]; grow[4 * q4 + 1] = v[1]; grow[4 * q4 + 2] = v[2]; grow[4 * q4 + 3] = v[3];
                         }
                         const float hold = h8[j];
