@@ -552,8 +552,15 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
             posted = false;
             if (ahead && behind_sweeps) ONMF_TRY((*behind_sweeps)());
             // a sweep evaluates the test of the one two sweeps back: the last two are still open
+            // (the records, and behind them the resolution's own words NEXT and NRES, reach the host through
+            // memory the last of these kernels writes)
+            if (!c->rec_pinned) {
+                HIP_TRY(c, hipHostMalloc((void**)&c->rec_pinned, (size_t)(4 * SCREEN_MAX_SWEEPS + 4) * sizeof(float),
+                                         hipHostMallocMapped));
+                HIP_TRY(c, hipHostGetDevicePointer((void**)&c->rec_pinned_dev, c->rec_pinned, 0));
+            }
             ONMF_TRY(launch_screen_final(c, base, std::max(start, sub_iter - 2), sub_iter - 1, (float)tol,
-                                         (float)rank_cap, s, nullptr, cw_rows));
+                                         (float)rank_cap, s, nullptr, cw_rows, c->rec_pinned_dev));
             for (int rd = 0; rd < dev_rounds; ++rd) {
                 const int* next = reinterpret_cast<const int*>(base) + ScreenLayout::NEXT;
                 ONMF_TRY(launch_screen_resolve(c, base, r, b, buf, sub_iter, (float)tol, s));
@@ -562,14 +569,9 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
                 ONMF_TRY(profile_mark(c, s));
                 ONMF_TRY(launch_sweep(c, r, b, Gm, Cm, buf, alpha, 0, 0, sub_iter, (double*)c->stats.p, &groups, s, &sc2));
                 ONMF_TRY(profile_mark(c, s));
-                ONMF_TRY(launch_screen_final(c, base, 0, sub_iter - 1, (float)tol, (float)rank_cap, s, next, cw_rows));
+                ONMF_TRY(launch_screen_final(c, base, 0, sub_iter - 1, (float)tol, (float)rank_cap, s, next, cw_rows,
+                                             c->rec_pinned_dev));
             }
-            // (the records, and behind them the resolution's own words: NEXT, NRES)
-            if (!c->rec_pinned)
-                HIP_TRY(c, hipHostMalloc((void**)&c->rec_pinned, (size_t)(4 * SCREEN_MAX_SWEEPS + 4) * sizeof(float),
-                                         hipHostMallocDefault));
-            HIP_TRY(c, hipMemcpyAsync(c->rec_pinned, base + ScreenLayout::REC,
-                                      (size_t)(4 * SCREEN_MAX_SWEEPS + 4) * sizeof(float), hipMemcpyDeviceToHost, s));
             if (ahead) {
                 // the host waits for the records only; the follow-up work is already behind them
                 if (!c->ev_rec) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_rec, hipEventDisableTiming));

@@ -105,7 +105,8 @@ struct onmf_ctx {
     // verdicts looked at by the next call instead of this one
     int defer_verdict = 0;                // ONMF_OPT_DEFER_VERDICT
     PendingSolve pend;
-    float* rec_pinned = nullptr;          // host staging of the verdict records (its own: a pending solve keeps it)
+    float* rec_pinned = nullptr;          // the verdict records in host memory the device writes (screen_final_kernel)
+    float* rec_pinned_dev = nullptr;      // the same memory as the device addresses it
     long long sweeps_total = 0;           // sweeps of all settled solves
     long long n_deferred_redone = 0;      // deferred solves that had to be run again
     // NumPy's MT19937 stream on the device (mt19937.hip): jump table, head words, chunk blocks, final block
@@ -436,7 +437,7 @@ int launch_screen_init(onmf_ctx* c, float* base, int r, hipStream_t s, int n_set
 // cw_rows: screen_cw_rows(r) when the sweeps were the tile kernel's (they carry the Collatz-Wielandt sums);
 // the kernel then also takes one power step of the positive vector on the last sweep's sums
 int launch_screen_final(onmf_ctx* c, float* base, int k_from, int k_last, float tol, float rank_cap,
-                        hipStream_t s, const int* start_dev = nullptr, int cw_rows = 0);
+                        hipStream_t s, const int* start_dev = nullptr, int cw_rows = 0, float* rec_host = nullptr);
 // r <= 64: settle the first inconclusive verdict in the records on the device - both Gram matrices, their
 // top eigenvalues, the reference's comparison - and prepare the launch enqueued behind it (first sweep in
 // ScreenLayout::NEXT, flag and accumulator sets reopened).  Does nothing if there is none to settle.
