@@ -381,9 +381,10 @@ double onmf_host_lambda_max(const float* S_host, int n);
  *                          evaluates every inconclusive test.  Same sweep counts and codes either way.
  *   ONMF_OPT_LARS_SLOTS    onmf_sparse_code_lars keeps, per column, the inverse Gram matrix of the active atoms in
  *                          LDS.  Room for all r atoms lets only a few wavefronts be resident per CU, so a call
- *                          sizes its launch by the most atoms any column of the PREVIOUS call held at a time
- *                          (plus a quarter; 16, 32, 48 or 64 slots) and codes the columns that need more in a
- *                          second launch with room for r (ONMF_CNT_LARS_RECODED counts them).  0 (default):
+ *                          sizes its launch by how many columns of the PREVIOUS call needed more than 16, 32,
+ *                          48 and 64 slots (the smallest of these that all but 1 column in 64 fitted in; a first
+ *                          call tries 64) and codes the columns that need more in a second launch with room
+ *                          for r (ONMF_CNT_LARS_RECODED counts them).  0 (default):
  *                          that rule; n > 0: n slots (at most 64, or r) in the first launch whatever the
  *                          history.  Same codes either way.
  *   ONMF_OPT_DEFER_VERDICT != 0: onmf_step calls that return no host scalars do not wait for the stopping test's
