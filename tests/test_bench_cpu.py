@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 
 def test_step_flops_match_the_survey_figures():
     import bench
-    # SURVEY: headline 163.5 GF, C2 2.90 GF, C4 370.4 GF per step at 10 sweeps
+    # headline 163.5 GF, C2 2.90 GF, C4 370.4 GF per step at 10 sweeps (2 d r b for each of W^T X and H X^T, 2 r^2 b per sweep and for H H^T)
     assert abs(bench.step_flops(1024, 256, 65536, 10) / 1e9 - 163.5) < 0.1
     assert abs(bench.step_flops(1024, 64, 8192, 10) / 1e9 - 2.90) < 0.01
     assert abs(bench.step_flops(4096, 256, 65536, 10) / 1e9 - 370.4) < 0.1
