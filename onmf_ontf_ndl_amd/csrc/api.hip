@@ -432,21 +432,24 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
                                    nullptr, Cm + (b - tail_cols), b, 0.f, nullptr, Gm, r, ps, &c->slab_prep);
     else if (!one_product)
         prep_rc = launch_gemm(c, true, true, r, r, d, W, r, W, r, 1.f, 0.f, nullptr, Gm, r, ps, &c->slab_prep);
-    if (prep_rc == ONMF_OK) {
-        if (H0) {
-            if (H0 != buf[0] &&
-                hipMemcpyAsync(buf[0], H0, rb * sizeof(float), hipMemcpyDeviceToDevice, ps) != hipSuccess)
-                prep_rc = onmf_fail(c, ONMF_ERR_HIP, "sparse_code: copy of H0 failed");
-        } else {
-            prep_rc = launch_fill_uniform(buf[0], rb, seed, ps);
-        }
-    }
     const double tol = (double)stopping_diff;
     const double rank_cap = (double)std::min(r, b);
     const int exact_cd = (coder_mode == ONMF_CODER_EXACT_CD);
     const bool screened = !exact_cd && !within_radius && tol >= 0.0 && !c->exact_stop && c->screen_stop &&
                           c->sweep_kernel != 1 && sweep_tile_covers(r, b) &&
                           sub_iter <= SCREEN_MAX_SWEEPS && keep_sweeping(1.0, tol);
+    // one stream, start code drawn here, screened test: the draw rides in the screen's set-up launch (a
+    // short step is a chain of launches, and each one costs the host and the device about 5 us)
+    const bool fill_with_init = one_product && screened && H0 == nullptr && rb > 0;
+    if (prep_rc == ONMF_OK) {
+        if (H0) {
+            if (H0 != buf[0] &&
+                hipMemcpyAsync(buf[0], H0, rb * sizeof(float), hipMemcpyDeviceToDevice, ps) != hipSuccess)
+                prep_rc = onmf_fail(c, ONMF_ERR_HIP, "sparse_code: copy of H0 failed");
+        } else if (!fill_with_init) {
+            prep_rc = launch_fill_uniform(buf[0], rb, seed, ps);
+        }
+    }
     int init_rc = ONMF_OK;
     const bool probes_new = c->screen_r != r;     // (the set-up below records r)
     if (screened) {
@@ -461,7 +464,9 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
 #else
         init_rc = onmf_reserve(c, c->screen, (size_t)ScreenLayout::TOTAL * sizeof(float), "stop-test screen");
 #endif
-        if (init_rc == ONMF_OK) init_rc = launch_screen_init(c, (float*)c->screen.p, r, s, sub_iter + 1);
+        if (init_rc == ONMF_OK)
+            init_rc = launch_screen_init(c, (float*)c->screen.p, r, s, sub_iter + 1, fill_with_init ? buf[0] : nullptr,
+                                         fill_with_init ? rb : 0, seed);
     }
     int cm_rc = init_rc;
     if (cm_rc == ONMF_OK) {

@@ -265,6 +265,41 @@ int launch_ndl_chains(int n, const int* row_ptr, const int* nbr, int k, const in
 int launch_ndl_edge_accumulate(int n, int k, int T, const int* emb_trace, const float* R, int ldr, float* sum,
                                float* count, hipStream_t s);
 
+// Philox4x32-10 counter-based generator (one round; ten of them with the keys stepped give 4 x 32 random bits
+// per counter): the device's own uniform draws.
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+
+// U[0,1) floats 4q .. 4q+3 of the stream keyed by `seed` into out (n floats in all)
+__device__ __forceinline__ void fill_uniform_quad(float* __restrict__ out, size_t n, size_t q, uint64_t seed) {
+    uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32), 0u, 0u};
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int rd = 0; rd < 10; ++rd) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (float)(c[e] >> 8) * (1.0f / 16777216.0f);   // [0,1)
+    const size_t base = q * 4;
+    if (base + 3 < n && (((uintptr_t)(out + base)) & 15) == 0) {
+        *reinterpret_cast<float4*>(out + base) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (base + e < n) out[base + e] = v[e];
+    }
+}
+
 // Stopping-test screen: state layout and kernels.
 // first of the eight words of onmf_ctx::host_events that the LARS coder's last kernel writes: most slots a column
 // used, r, columns recoded so far, columns that needed more than 16 / 32 / 48 / 64 slots, columns coded
@@ -431,7 +466,8 @@ __device__ __forceinline__ int screen_eval_wave(float* base, int j, float& ub, f
 #endif
 
 // n_sets: accumulator sets to clear (the solve's sweeps)
-int launch_screen_init(onmf_ctx* c, float* base, int r, hipStream_t s, int n_sets = SCREEN_MAX_SWEEPS);
+int launch_screen_init(onmf_ctx* c, float* base, int r, hipStream_t s, int n_sets, float* fill_out = nullptr,
+                       size_t fill_n = 0, uint64_t fill_seed = 0);
 // the verdicts that no sweep of the launch evaluated: sweeps k_from .. k_last, in order
 // (start_dev not null: k_from = max(*start_dev, k_last - 1), nothing if *start_dev > k_last)
 // cw_rows: screen_cw_rows(r) when the sweeps were the tile kernel's (they carry the Collatz-Wielandt sums);

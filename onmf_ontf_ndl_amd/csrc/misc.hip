@@ -6,42 +6,12 @@
 
 namespace {
 
-// Philox4x32-10 counter-based generator: 4 uniform floats per counter.
-__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
-    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
-    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
-    const uint32_t n1 = (uint32_t)p1;
-    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
-    const uint32_t n3 = (uint32_t)p0;
-    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-}
-
 __global__ __launch_bounds__(256) void fill_uniform_kernel(float* __restrict__ out, size_t n,
                                                             uint64_t seed) {
     const size_t nquads = (n + 3) / 4;
     for (size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x; q < nquads;
-         q += (size_t)gridDim.x * blockDim.x) {
-        uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32), 0u, 0u};
-        uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll
-        for (int rd = 0; rd < 10; ++rd) {
-            philox_round(c, k0, k1);
-            k0 += 0x9E3779B9u;
-            k1 += 0xBB67AE85u;
-        }
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (float)(c[e] >> 8) * (1.0f / 16777216.0f);   // [0,1)
-        const size_t base = q * 4;
-        if (base + 3 < n && (((uintptr_t)(out + base)) & 15) == 0) {
-            *reinterpret_cast<float4*>(out + base) = make_float4(v[0], v[1], v[2], v[3]);
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (base + e < n) out[base + e] = v[e];
-        }
-    }
+         q += (size_t)gridDim.x * blockDim.x)
+        fill_uniform_quad(out, n, q, seed);
 }
 
 __global__ __launch_bounds__(256) void gather_columns_kernel(int d, int n, const float* __restrict__ X,

@@ -21,15 +21,6 @@
 
 namespace {
 
-__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
-    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
-    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
-    const uint32_t n1 = (uint32_t)p1;
-    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
-    const uint32_t n3 = (uint32_t)p0;
-    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-}
 
 __device__ __forceinline__ uint32_t chain_draw(uint64_t seed, uint64_t step, uint32_t chain, uint32_t slot) {
     uint32_t c[4] = {(uint32_t)step, (uint32_t)(step >> 32), chain, slot >> 2};

@@ -28,7 +28,18 @@ __device__ __forceinline__ float hash_unit(unsigned x) {      // deterministic v
     return (float)(int)(x >> 8) * (1.0f / 8388608.0f) - 1.0f;
 }
 
-__global__ __launch_bounds__(256) void screen_init_kernel(float* base, int r, int keep_probes, int n_sets) {
+// Workgroup 0 sets the screen's state up; the others (if any) draw the solve's start code, fill_n uniform
+// floats keyed by fill_seed, exactly as fill_uniform_kernel would.
+__global__ __launch_bounds__(256) void screen_init_kernel(float* base, int r, int keep_probes, int n_sets,
+                                                          float* __restrict__ fill_out, size_t fill_n,
+                                                          uint64_t fill_seed) {
+    if (blockIdx.x > 0) {
+        const size_t nquads = (fill_n + 3) / 4;
+        for (size_t q = (blockIdx.x - 1) * (size_t)blockDim.x + threadIdx.x; q < nquads;
+             q += (size_t)(gridDim.x - 1) * blockDim.x)
+            fill_uniform_quad(fill_out, fill_n, q, fill_seed);
+        return;
+    }
     const int tid = threadIdx.x;
     const float scale = 1.0f / sqrtf((float)r);              // |u_p|^2 <= r * scale^2 = 1
     // keep_probes: the probe vectors left by the previous solve (same r) are a better start than
@@ -686,11 +697,16 @@ int launch_screen_cw(onmf_ctx* c, float* base, int r, int b, const float* H, int
     return ONMF_OK;
 }
 
-int launch_screen_init(onmf_ctx* c, float* base, int r, hipStream_t s, int n_sets) {
+int launch_screen_init(onmf_ctx* c, float* base, int r, hipStream_t s, int n_sets, float* fill_out, size_t fill_n,
+                       uint64_t fill_seed) {
     const int keep = (c->screen_r == r) ? 1 : 0;
     c->screen_r = r;
     n_sets = std::max(1, std::min(n_sets, SCREEN_MAX_SWEEPS));
-    hipLaunchKernelGGL(screen_init_kernel, dim3(1), dim3(256), 0, s, base, r, keep, n_sets);
+    unsigned fill_blocks = 0;
+    if (fill_out != nullptr && fill_n > 0)
+        fill_blocks = (unsigned)std::min<size_t>(((fill_n + 3) / 4 + 255) / 256, 4096);
+    hipLaunchKernelGGL(screen_init_kernel, dim3(1 + fill_blocks), dim3(256), 0, s, base, r, keep, n_sets, fill_out,
+                       fill_n, fill_seed);
     HIP_TRY(c, hipGetLastError());
     return ONMF_OK;
 }
