@@ -95,3 +95,20 @@ def test_core_shares_for_rank_pinning():
             assert got and set(got) <= before and os.sched_getaffinity(0) == set(got)
         finally:
             os.sched_setaffinity(0, before)
+
+
+def test_whole_step_traffic_record_feeds_the_bench_line():
+    """`step_hbm` of the bench line: bytes per step from the committed counter passes over this run's time per
+    step, for the shape the passes were taken at only; the hash over the library's sources is stable."""
+    import bench
+    d, r, b = bench.WORKLOADS["headline"]
+    rec = bench.measured_step_hbm(d, r, b, 1.5)
+    assert rec is not None, "profiles/ holds no *_step_hbm_traffic.json for the headline shape"
+    assert rec["unit"] == "GB/s" and rec["peak"] == bench.PEAK_HBM_GBPS
+    assert abs(rec["achieved"] - rec["bytes_per_step"] / 1.5e-3 / 1e9) < 1e-6 * rec["achieved"]
+    assert abs(rec["frac"] - rec["achieved"] / rec["peak"]) < 1e-12
+    # a fused step cannot move less than X once, H once and the small matrices
+    assert rec["bytes_per_step"] > rec["algorithmic_bytes_per_step"] > 4.0 * d * b
+    assert isinstance(rec["sources_unchanged"], bool)
+    assert bench.measured_step_hbm(d, r, b // 2, 1.5) is None          # another shape: no figure
+    assert bench.csrc_sha256() == bench.csrc_sha256() and len(bench.csrc_sha256()) == 64
