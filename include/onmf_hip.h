@@ -390,6 +390,13 @@ double onmf_host_lambda_max(const float* S_host, int n);
  *   ONMF_OPT_DEFER_VERDICT != 0: onmf_step calls that return no host scalars do not wait for the stopping test's
  *                          verdicts; see onmf_settle.  0 (default): every call's outputs are final when it returns
  *                          (in stream order).
+ *   ONMF_OPT_VERDICT_LAG3  != 0 (default): one-launch solves on the 64-column kernel (batches of up to 64 columns per
+ *                          CU) act on a sweep's stopping test three sweeps later instead of two, so that no wave
+ *                          waits for a verdict: a stop leaves two sweeps run in vain instead of one, and a test
+ *                          the bounds cannot decide can no longer be evaluated in full (its input is
+ *                          overwritten) - the solve is then run again in the plain form (counted by
+ *                          ONMF_CNT_LAG3_REDONE / ONMF_CNT_DEFERRED_REDONE).  Used only when the start code can be
+ *                          had again and the previous solve needed no host decision.  Same results either way.
  *   ONMF_OPT_GEMM_TAIL     experiment, off (0) by default: 100 * p + n computes the last p per cent of the tiles of
  *                          the big W^T X launch in n pieces along the contraction, summed by a small kernel
  *                          (measured: no gain at any setting; results differ from the default in the last bits
@@ -417,6 +424,7 @@ double onmf_host_lambda_max(const float* S_host, int n);
 #define ONMF_OPT_LARS_SLOTS 10
 #define ONMF_OPT_DEFER_VERDICT 11
 #define ONMF_OPT_GEMM_TAIL 12
+#define ONMF_OPT_VERDICT_LAG3 13
 int onmf_set_option(onmf_ctx* ctx, int key, int value);
 /*
  * Event counters since onmf_create (no counterpart in the reference):
@@ -433,6 +441,8 @@ int onmf_set_option(onmf_ctx* ctx, int key, int value);
                                         flight are not in the count yet) */
 #define ONMF_CNT_SWEEPS_TOTAL 7       /* sweeps run by all settled solves (what sweeps_done would have summed to) */
 #define ONMF_CNT_DEFERRED_REDONE 8   /* deferred steps (ONMF_OPT_DEFER_VERDICT) whose solve had to be run again */
+#define ONMF_CNT_LAG3_REDONE 9       /* waited-for solves run again because a test acted on three sweeps later came out
+                                        inconclusive (ONMF_OPT_VERDICT_LAG3; deferred steps count under 8) */
 #define ONMF_CNT_LARS_SLOTS_USED 6   /* not a count: the most atoms a column of the last completed
                                         onmf_sparse_code_lars call held at a time */
 int onmf_get_counter(onmf_ctx* ctx, int which, long long* value);

@@ -27,6 +27,8 @@ OPT_SPIN_LIMIT_MS = 8
 OPT_DEVICE_RESOLVE = 9
 OPT_LARS_SLOTS = 10
 OPT_DEFER_VERDICT = 11
+OPT_GEMM_TAIL = 12
+OPT_VERDICT_LAG3 = 13
 CNT_SWEEP_TIMEOUTS = 1
 CNT_DICT_TIMEOUTS = 2
 CNT_FALLBACK_SOLVES = 3
@@ -35,6 +37,7 @@ CNT_LARS_RECODED = 5
 CNT_LARS_SLOTS_USED = 6
 CNT_SWEEPS_TOTAL = 7
 CNT_DEFERRED_REDONE = 8
+CNT_LAG3_REDONE = 9
 NDL_GLAUBER = 0
 NDL_PIVOT = 1
 

@@ -202,6 +202,7 @@ int onmf_set_option(onmf_ctx* c, int key, int value) {
         case ONMF_OPT_LARS_SLOTS: c->lars_slots = value < 0 ? 0 : value; return ONMF_OK;
         case ONMF_OPT_DEFER_VERDICT: c->defer_verdict = value; return ONMF_OK;
         case ONMF_OPT_GEMM_TAIL: c->gemm_tail = value < 0 ? 0 : value; return ONMF_OK;
+        case ONMF_OPT_VERDICT_LAG3: c->lag3 = value; return ONMF_OK;
         case ONMF_OPT_SPIN_LIMIT_MS:
             c->spin_limit = value == -2 ? SPIN_FORCE_TIMEOUT
                                         : value < 0 ? -1LL : (long long)value * 100000LL;      // 100 MHz ticks
@@ -226,6 +227,7 @@ int onmf_get_counter(onmf_ctx* c, int which, long long* value) {
             return ONMF_OK;
         case ONMF_CNT_SWEEPS_TOTAL: *value = c->sweeps_total; return ONMF_OK;
         case ONMF_CNT_DEFERRED_REDONE: *value = c->n_deferred_redone; return ONMF_OK;
+        case ONMF_CNT_LAG3_REDONE: *value = c->n_lag3_redone; return ONMF_OK;
         case ONMF_CNT_LARS_SLOTS_USED:
             *value = c->host_events ? ((volatile int*)c->host_events)[ONMF_LARS_HOST_WORDS] : 0;
             return ONMF_OK;
@@ -522,7 +524,16 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
             // (with one launch per sweep every count is complete before the launch that reads it starts:
             // the forced timeout of the tests applies to one-launch solves only)
             const long long spin = (!persistent && c->spin_limit == SPIN_FORCE_TIMEOUT) ? -1LL : c->spin_limit;
-            const ScreenDev sc = {base, start, (float)tol, (float)rank_cap, spin /* 2 s by default */};
+            ScreenDev sc = {base, start, (float)tol, (float)rank_cap, spin /* 2 s by default */};
+            // Kernels with a control wave may act on a test three sweeps later instead of two - their tile waves
+            // then never wait for a verdict.  The price: at an inconclusive test the stopping sweep's input is
+            // gone (overwritten by the second sweep that ran ahead), so the host cannot evaluate the test in
+            // full and runs the solve again in the plain form instead.  Only where that is possible (the start
+            // code can be had again) and unlikely (the previous solve needed no host decision).
+            const bool start_again = H0 == nullptr || (H0 != buf[0] && H0 != buf[1] && H0 != buf[2]);
+            const bool lag3 = persistent && c->lag3 && !second_try && start_again && !c->screen_last_undecided &&
+                              sub_iter >= 4 && sweep_has_control_wave_at(c, r, b);
+            sc.lag = lag3 ? 3 : 2;
             int i = start;
             // When the probes are due for a power step, it is taken on the move of the SECOND sweep (the
             // first one is the jump away from the random start; the later moves resemble each other
@@ -656,6 +667,14 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
                     // lower bound.
                     if (dist_trace) dist_trace[i] = rec[4 * i + 0];
                     continue;
+                }
+                if (lag3) {
+                    // the stopping sweep's input is gone (two sweeps ran ahead): the plain form, from the start
+                    c->screen_last_undecided = true;
+                    c->screen_refresh_due = true;
+                    ++c->n_lag3_redone;
+                    return sparse_code_impl(c, d, r, b, X, ldx, W, H0, seed, alpha, sub_iter, stopping_diff, coder_mode, H,
+                                            sweeps_done, dist_trace, s, after, after_valid, false, behind_sweeps, nullptr);
                 }
                 double dist = nan;                        // bounds straddle tol: evaluate in full
                 undecided = true;

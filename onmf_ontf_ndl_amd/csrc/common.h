@@ -77,6 +77,8 @@ struct onmf_ctx {
     hipEvent_t ev_prep_fork = nullptr, ev_prep_join = nullptr;
     DevBuf slab_prep;               // split-K slabs of products issued on the preparation stream
     int overlap_dict = 1;
+    int lag3 = 1;               // control-wave kernels may act on a test three sweeps later (ONMF_OPT_VERDICT_LAG3)
+    long long n_lag3_redone = 0;    // solves run again because such a test came out inconclusive
     int gemm_tail = 0;          // finer grain at the end of the big W^T X launch: 100 * percent of tiles + pieces (0: off)
     int screen_stop = 1;
     int screen_r = -1;              // r of the probes currently held in `screen`
@@ -206,7 +208,10 @@ struct ScreenDev {
     long long spin_limit;    // bound (100 MHz ticks) on waiting for the other workgroups' sums
     const int* start_dev;    // not null: the launch's first sweep is read from here (and is its v_first), ...
     int k_end;               // ... its last sweep is k_end - 1
+    int lag;                 // kernels with a control wave: 3 = act on a test three sweeps later (see sweep_tile.h); else two
 };
+// whether the sweeps of a screened solve at this shape come from the kernel with a control wave
+bool sweep_has_control_wave_at(onmf_ctx* c, int r, int b);
 
 // Per-column stopping (many independent one-column solves in one launch).
 struct EachStop {

@@ -211,6 +211,10 @@ static bool use_medium_workgroups(onmf_ctx* c, int r, int b, bool probing) {
     return probing && c->sweep_kernel == 0 && !use_small_workgroups(c, r, b, probing) && (b + 127) / 128 <= cu_count(c);
 }
 
+bool sweep_has_control_wave_at(onmf_ctx* c, int r, int b) {
+    return sweep_tile_covers(r, b) && c->sweep_kernel != 1 && use_small_workgroups(c, r, b, true);
+}
+
 int sweep_tile_workgroups(onmf_ctx* c, int r, int b, bool probing) {
     if (use_small_workgroups(c, r, b, probing)) return (b + 63) / 64;
     if (use_medium_workgroups(c, r, b, probing)) return (b + 127) / 128;

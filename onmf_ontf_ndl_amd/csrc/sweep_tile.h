@@ -96,15 +96,27 @@ __device__ __forceinline__ float row_sum16(float x) {
 // comes with 4 waves (64 columns) per workgroup: a batch of a few thousand columns then spreads over
 // that many more CUs with one wave per SIMD each, instead of four waves sharing every SIMD's matrix
 // pipe on a few CUs while the rest of the chip idles.
+// The probing kernel with one tile per wave and four tile waves per workgroup (batches of a few thousand columns:
+// sweeps of a few microseconds) comes with a FIFTH wave that owns no tile: the control wave.  What a sweep's
+// synchronisation costs - the workgroup's atomics out and back, the look at the other workgroups' count, the
+// round trip for their sums, the test's arithmetic: 3 us a sweep, as much as the sweep's own work - it does
+// while the tile waves are in the NEXT sweep's block loop: during sweep k it posts the workgroup's sums of
+// sweep k - 1 (double-buffered in LDS), waits for every workgroup's, evaluates that sweep's test and leaves
+// the verdict for the top of sweep k + 1.  Same verdicts at the same sweeps as the other forms (a test is
+// acted on two sweeps later), one barrier less per sweep, and nothing of it on the tile waves' path.
+template <int NB, bool HALF, bool PROBE, int CT, bool EACH, int WPG>
+constexpr bool sweep_has_control_wave() { return PROBE && !EACH && CT == 1 && WPG == 4; }
+
 template <int NB, bool HALF, bool PROBE, int CT, bool EACH = false, int WPG = 16 / CT>
-__global__ __launch_bounds__(64 * WPG) void sweep_tile_kernel(
+__global__ __launch_bounds__(64 * WPG + (sweep_has_control_wave<NB, HALF, PROBE, CT, EACH, WPG>() ? 64 : 0)) void sweep_tile_kernel(
     int r, int b, const float* __restrict__ Gm, const float* __restrict__ Cm, float* hb0, float* hb1,
     float* hb2, float alpha, int exact_cd, int k_first_arg, int k_count_arg, double* __restrict__ stats,
     ScreenDev sc, EachStop es) {
     static_assert(!EACH || (!PROBE && CT == 1), "per-column stopping: plain kernel, one tile per wave");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NBLK = HALF ? NB * (NB + 1) / 2 : NB * NB;
-    constexpr int NT = 64 * WPG;           // threads per workgroup
+    constexpr int NT = 64 * WPG;           // threads per workgroup that own tiles
+    constexpr bool CTRL = sweep_has_control_wave<NB, HALF, PROBE, CT, EACH, WPG>();
     // Two tiles per wave: the in-block update runs on both at once.  A v_permlane16_swap of the two tiles'
     // registers leaves lane group g with 8 consecutive rows (8 (g >> 1) .. + 7) of ONE column of tile g & 1;
     // the rows are then updated in order inside the lane, first half of the block in the lower half of the
@@ -130,6 +142,14 @@ __global__ __launch_bounds__(64 * WPG) void sweep_tile_kernel(
     // instructions per sweep for these small ranks, where borderline tests are frequent.
     constexpr bool CWB = PROBE && NB <= SCREEN_CW_ROWS / 16;
     float* ywg = p2wg + 24;                                 // CWB: 16*NB workgroup partial sums of y
+    // CTRL: the workgroup's partial sums exist twice (the set of sweep k is filled while the control wave sends
+    // off the set of sweep k - 1), and so does the verdict slot (written for the next sweep while this sweep's
+    // may still be read)
+    constexpr int SET_FLOATS = 24 + 16 * NB;
+    auto p2_of = [&](int set) -> float* { return p2wg + (CTRL ? set * SET_FLOATS : 0); };
+    auto sum_of = [&](int set) -> double* { return reinterpret_cast<double*>(p2_of(set) + 16); };
+    auto y_of = [&](int set) -> float* { return p2_of(set) + 24; };
+    auto verdict_of = [&](int slot) -> int* { return verdict_s + (CTRL ? slot : 0); };
 
     const int tid = threadIdx.x;
     int k_first = k_first_arg, k_count = k_count_arg, v_first = sc.v_first;
@@ -148,6 +168,85 @@ __global__ __launch_bounds__(64 * WPG) void sweep_tile_kernel(
 
     const int lane = tid & 63;
     const int wave = tid >> 6;
+    if constexpr (CTRL) {
+        if (wave == WPG) {
+            // ---- the control wave ----
+            float ubc = sc.base[ScreenLayout::UBH + v_first];
+            const int cw = CWB ? 16 * NB : 0;
+            auto wait_count = [&](int j) -> bool {         // every workgroup's sums of sweep j in place? (bounded)
+                const int* cnt = reinterpret_cast<const int*>(sc.base) + ScreenLayout::CNT + j;
+                const long long t0 = wall_clock64();
+                for (;;) {
+                    // (a limit of SPIN_FORCE_TIMEOUT makes the wait fail even when the count is complete: the
+                    // host's way to exercise the recovery path)
+                    if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (int)gridDim.x &&
+                        sc.spin_limit != SPIN_FORCE_TIMEOUT)
+                        return true;
+                    if (wall_clock64() - t0 > sc.spin_limit) return false;          // wave-uniform (one clock value)
+                    __builtin_amdgcn_s_sleep(4);
+                }
+            };
+            auto test_of = [&](int j) -> int {             // verdict of sweep j (0 = go on)
+                if (!wait_count(j)) {
+                    if (lane == 0)
+                        __hip_atomic_store(reinterpret_cast<int*>(sc.base) + ScreenLayout::FLAG, SCREEN_FLAG_TIMEOUT,
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    return SCREEN_FLAG_TIMEOUT;
+                }
+                return screen_eval_wave(sc.base, j, ubc, sc.tol, sc.rank_cap, blockIdx.x == 0, -1.0f, cw);
+            };
+            auto post_sums = [&](int j) {                  // this workgroup's sums of sweep j, then its count
+                float* cur = sc.base + ScreenLayout::SETS + j * ScreenLayout::SETSZ;
+                const int rep = blockIdx.x % SCREEN_REPL;
+                float back_f = 0.f;
+                double back_d = 0.0;
+                if (lane < 16) {
+                    back_f = atomicAdd(&cur[ScreenLayout::SET_P2 + rep * 16 + lane], p2_of(j & 1)[lane]);
+                } else if (lane < 18) {
+                    back_d = atomicAdd(reinterpret_cast<double*>(cur + ScreenLayout::SET_SUMS) + rep * 2 + (lane - 16),
+                                       sum_of(j & 1)[lane - 16]);
+                }
+                if (CWB) {
+                    const int yrep = blockIdx.x % SCREEN_YREPL;
+                    for (int q = lane; q < 16 * NB; q += 64)
+                        back_d += atomicAdd(reinterpret_cast<double*>(cur + ScreenLayout::SET_Y) + yrep * SCREEN_CW_ROWS + q,
+                                            (double)y_of(j & 1)[q]);
+                }
+                // (they return, and the count goes out only after every one of them has: whoever sees the
+                // count complete finds all sums in place, without any cache maintenance)
+                asm volatile("s_waitcnt vmcnt(0)" ::"v"(back_f), "v"(back_d) : "memory");
+                if (lane == 0)
+                    __hip_atomic_fetch_add(reinterpret_cast<int*>(sc.base) + ScreenLayout::CNT + j, 1, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+            };
+            // the verdict the first sweep of the launch starts with (its sums were all posted before the launch)
+            // sc.lag = 2: the test of sweep k - 1 is evaluated during sweep k, behind this workgroup's own sums
+            // of that sweep - it waits for the other workgroups' (the tile waves wait for it when their sweep
+            // is shorter than that chain).  sc.lag = 3 (the host's choice when it can run the solve again): the
+            // test of sweep k - 2, whose sums all went out a sweep ago - nothing to wait for, and the tile
+            // waves never wait.  A test is then acted on three sweeps later: two sweeps run ahead in vain at a
+            // stop, and the second of them overwrites the stopping sweep's input - which only an inconclusive
+            // test needs (the host's full evaluation); the host then runs that solve again.
+            const int lag = sc.lag == 3 ? 3 : 2;
+            int verdict = 0;
+            if (k_first - lag >= v_first) verdict = test_of(k_first - lag);    // (its sums went out in an earlier launch)
+            if (lane == 0) *verdict_of(k_first & 1) = verdict;
+            __syncthreads();
+            if (verdict != 0) return;
+            for (int k = k_first; k < k_first + k_count; ++k) {
+                __syncthreads();                           // the tile waves enter the block loop of sweep k
+                verdict = 0;
+                if (k - 1 >= k_first) post_sums(k - 1);
+                const int j = k + 1 - lag;
+                if (j >= v_first) verdict = test_of(j);
+                if (lane == 0) *verdict_of((k + 1) & 1) = verdict;
+                __syncthreads();                           // the tile waves' sums of sweep k are in LDS
+                if (verdict != 0) return;                  // (the tile waves leave at the top of sweep k + 1)
+            }
+            post_sums(k_first + k_count - 1);
+            return;
+        }
+    }
     const int c_lane = lane & 15;          // column of the tile (doubles as the A-operand row index)
     const int g_lane = lane >> 4;          // lane group: rows 4g .. 4g+3 of every block
 
@@ -264,9 +363,15 @@ __global__ __launch_bounds__(64 * WPG) void sweep_tile_kernel(
 #else
 #define SWEEP_MARK(i) do { } while (0)
 #endif
+    if constexpr (CTRL) __syncthreads();   // the control wave has left the verdict the first sweep starts with
     for (int k = k_first; k < k_first + k_count; ++k) {
         SWEEP_MARK(0);
-        if (PROBE) {
+        if constexpr (CTRL) {
+            // the test of sweep k - 2, evaluated by the control wave during sweep k - 1 (workgroup-uniform, and
+            // the same in every workgroup)
+            if (*verdict_of(k & 1) != 0) return;
+        }
+        if (PROBE && !CTRL) {
             // the test of sweep k - 2, once every workgroup's sums of that sweep are in
             if (wave == 0) {
                 int verdict = 0;
@@ -323,15 +428,15 @@ __global__ __launch_bounds__(64 * WPG) void sweep_tile_kernel(
                 }
             }
             if (PROBE) {
-                if (tid < 16) p2wg[tid] = 0.f;
-                if (tid < 2) sumwg[tid] = 0.0;
+                if (tid < 16) p2_of(k & 1)[tid] = 0.f;
+                if (tid < 2) sum_of(k & 1)[tid] = 0.0;
                 if (CWB)
-                    for (int j = tid; j < 16 * NB; j += NT) ywg[j] = 0.f;
+                    for (int j = tid; j < 16 * NB; j += NT) y_of(k & 1)[j] = 0.f;
             }
         }
         __syncthreads();
         SWEEP_MARK(1);
-        if (PROBE) {
+        if (PROBE && !CTRL) {
             if (*verdict_s != 0) return;   // workgroup-uniform, and the same in every workgroup
         }
 
@@ -676,8 +781,8 @@ __global__ __launch_bounds__(64 * WPG) void sweep_tile_kernel(
             stats[2 * slot + 0] = ds;
             stats[2 * slot + 1] = hh;
             if (PROBE) {
-                atomicAdd(&sumwg[0], ds);
-                atomicAdd(&sumwg[1], hh);
+                atomicAdd(&sum_of(k & 1)[0], ds);
+                atomicAdd(&sum_of(k & 1)[1], hh);
             }
         }
 
@@ -690,7 +795,7 @@ __global__ __launch_bounds__(64 * WPG) void sweep_tile_kernel(
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) e2 = fmaf(pacc[ct][t], pacc[ct][t], e2);
                 const float e = row_sum16(e2);
-                if (c == 15) atomicAdd(&p2wg[4 * g + t], e);
+                if (c == 15) atomicAdd(&p2_of(k & 1)[4 * g + t], e);
             }
             if constexpr (CWB) {
                 // t_col = v . H_new[:, col] (the lane's rows, then the four lane groups), y_row += H_new[row][col] t_col
@@ -714,12 +819,13 @@ __global__ __launch_bounds__(64 * WPG) void sweep_tile_kernel(
 #pragma unroll
                         for (int ct = 0; ct < CT; ++ct) yv = fmaf(h[ct][J][t], tcol[ct], yv);
                         yv = row_sum16(yv);
-                        if (c == 15) atomicAdd(&ywg[16 * J + 4 * g + t], yv);
+                        if (c == 15) atomicAdd(&y_of(k & 1)[16 * J + 4 * g + t], yv);
                     }
             }
             SWEEP_MARK(3);
             __syncthreads();
             SWEEP_MARK(4);
+            if constexpr (CTRL) continue;      // the control wave sends the sums off and evaluates the tests
             // One set of global atomics per workgroup, spread over replicas to keep contention low.
             // They return, and the count below goes out only after every one of them has: whoever
             // sees the count complete finds all sums in place, without any cache maintenance.
@@ -789,7 +895,9 @@ int run_tile(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm, float*
              int exact_cd, int k_first, int k_count, double* stats, int* n_groups, const ScreenDev& sc,
              hipStream_t s, EachStop es = EachStop{}) {
     constexpr int NBLK = HALF ? NB * (NB + 1) / 2 : NB * NB;
-    constexpr size_t lds = sizeof(float) * ((size_t)NBLK * 256 + 5 * NB * 16 + (PROBE ? (NB * 256 + 16 + 4 + 4 + 16 * NB) : 0));
+    constexpr bool CTRL = sweep_has_control_wave<NB, HALF, PROBE, CT, EACH, WPG>();
+    constexpr size_t lds = sizeof(float) * ((size_t)NBLK * 256 + 5 * NB * 16 + (PROBE ? (NB * 256 + 16 + 4 + 4 + 16 * NB) : 0) +
+                                            (CTRL ? (24 + 16 * NB) : 0));
     static_assert(lds <= 160 * 1024, "Gm blocks do not fit the LDS");
     static LdsLimit lim;
     ONMF_TRY(onmf_raise_lds_limit(c, lim, (const void*)sweep_tile_kernel<NB, HALF, PROBE, CT, EACH, WPG>, lds));
@@ -798,7 +906,7 @@ int run_tile(onmf_ctx* c, int r, int b, const float* Gm, const float* Cm, float*
     static_assert(WPG != 16 / CT || COLS == TILE_COLS_PER_WG, "the default geometry is 256 columns per workgroup");
     const int wgs = (b + COLS - 1) / COLS;
     *n_groups = wgs * WPG;
-    hipLaunchKernelGGL((sweep_tile_kernel<NB, HALF, PROBE, CT, EACH, WPG>), dim3(wgs), dim3(NT), lds, s, r, b, Gm, Cm,
+    hipLaunchKernelGGL((sweep_tile_kernel<NB, HALF, PROBE, CT, EACH, WPG>), dim3(wgs), dim3(NT + (CTRL ? 64 : 0)), lds, s, r, b, Gm, Cm,
                        hb[0], hb[1], hb[2], alpha, exact_cd, k_first, k_count, stats, sc, es);
     HIP_TRY(c, hipGetLastError());
     return ONMF_OK;

@@ -99,7 +99,7 @@ class Engine:
         for name, key in (("sweep_timeouts", _lib.CNT_SWEEP_TIMEOUTS), ("dict_timeouts", _lib.CNT_DICT_TIMEOUTS),
                           ("fallback_solves", _lib.CNT_FALLBACK_SOLVES),
                           ("device_resolves", _lib.CNT_DEVICE_RESOLVES), ("lars_recoded", _lib.CNT_LARS_RECODED), ("lars_slots_used", _lib.CNT_LARS_SLOTS_USED), ("sweeps_total", _lib.CNT_SWEEPS_TOTAL),
-                          ("deferred_redone", _lib.CNT_DEFERRED_REDONE)):
+                          ("deferred_redone", _lib.CNT_DEFERRED_REDONE), ("lag3_redone", _lib.CNT_LAG3_REDONE)):
             v = C.c_longlong(0)
             _lib.check(self.lib.onmf_get_counter(self.ctx, key, C.byref(v)), self.ctx, "onmf_get_counter")
             out[name] = int(v.value)

@@ -332,3 +332,36 @@ def test_steps_that_do_not_wait_for_their_verdicts(eng, d, r, b, tol_kind):
     print("d=%d r=%d b=%d tol=%.4g: sweeps %s, deferred chain: %d solves run again" % (d, r, b, tol, sw1, redone))
     assert all(s is None for s in sw2) and n1 == sum(sw1) == n2
     assert torch.equal(W1, W2) and torch.equal(A1, A2) and torch.equal(B1, B2) and torch.equal(H1, H2)
+
+
+@pytest.mark.parametrize("d,r,b", [(100, 16, 1000), (200, 64, 3000), (120, 100, 2048), (64, 256, 3000)])
+def test_tests_acted_on_three_sweeps_later_change_nothing(eng, d, r, b):
+    """The kernels with a control wave (64 columns per workgroup) may act on a sweep's test three sweeps later
+    instead of two, so that no wave ever waits for a verdict (ONMF_OPT_VERDICT_LAG3, the default): same sweep
+    counts and the same bits as with the option off and as the full test - for tolerances that never stop,
+    that stop in the middle (at every sweep in turn: a stop now leaves two sweeps run in vain) and that hug a
+    sweep's dist so closely that the bounds cannot decide (the solve is then run again in the plain form)."""
+    import torch
+    LAG3 = 13
+    g = torch.Generator(device=eng.device).manual_seed(11 * d + r)
+    X = torch.rand(d, b, device=eng.device, generator=g)
+    W = torch.rand(d, r, device=eng.device, generator=g)
+    W = W / torch.clamp(torch.linalg.norm(W, dim=0), min=1.0)
+    H0 = torch.rand(r, b, device=eng.device, generator=g)
+    eng.set_option(EXACT, 1)
+    _, _, trace = eng.sparse_code(X, W, H0=H0, alpha=0.05, sub_iter=12, stopping_diff=0.0)
+    eng.set_option(EXACT, 0)
+    dists = [float(v) for v in trace[:11]]
+    tols = [0.0] + [0.5 * (dists[i] + dists[i + 1]) for i in range(0, 10)] + [dists[4] * (1 + 1e-6), dists[7] * (1 - 1e-6)]
+    for tol in tols:
+        eng.set_option(EXACT, 1)
+        He, se, _ = eng.sparse_code(X, W, H0=H0, alpha=0.05, sub_iter=12, stopping_diff=tol)
+        eng.set_option(EXACT, 0)
+        for lag3 in (1, 0, 1):
+            eng.set_option(LAG3, lag3)
+            try:
+                H, s, _ = eng.sparse_code(X, W, H0=H0, alpha=0.05, sub_iter=12, stopping_diff=tol)
+            finally:
+                eng.set_option(LAG3, 1)
+            assert s == se, (tol, lag3, s, se)
+            assert torch.equal(H, He), (tol, lag3)
