@@ -373,12 +373,14 @@ double onmf_host_lambda_max(const float* S_host, int n);
  *   ONMF_OPT_PERSISTENT_SWEEPS != 0 (default): with the screened stopping test, run all sweeps of
  *                          a solve in one launch when its grid (one workgroup per 256 columns)
  *                          fits the chip's CUs; 0: one launch per sweep.
- *   ONMF_OPT_DEVICE_RESOLVE != 0: for r <= 64, when the previous solve needed a full evaluation of the
- *                          stopping test, the next one-launch solve carries one round of device-side
- *                          resolution (both Gram matrices and their top eigenvalues computed on the GPU,
- *                          the sweeps continued from there) so that the host is not in the loop; 0
- *                          (default: the kernel does not yet beat the host's round trip): the host
- *                          evaluates every inconclusive test.  Same sweep counts and codes either way.
+ *   ONMF_OPT_DEVICE_RESOLVE != 0: for r <= 64, when the previous solve needed full evaluations of the
+ *                          stopping test, the next one-launch solve carries as many rounds (four at most) of
+ *                          device-side resolution (both Gram matrices and their top eigenvalues computed on
+ *                          the GPU - Householder tridiagonalisation for r <= 32, Lanczos above, multisection
+ *                          - the sweeps continued from there) so that the host is not in the loop; 0
+ *                          (default: a round costs 47 us and three launches at r = 25, which does not beat
+ *                          the host's round trip): the host evaluates every inconclusive test.  Same sweep
+ *                          counts and codes either way.
  *   ONMF_OPT_LARS_SLOTS    onmf_sparse_code_lars keeps, per column, the inverse Gram matrix of the active atoms in
  *                          LDS.  Room for all r atoms lets only a few wavefronts be resident per CU, so a call
  *                          sizes its launch by how many columns of the PREVIOUS call needed more than 16, 32,

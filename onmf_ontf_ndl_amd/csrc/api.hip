@@ -507,6 +507,7 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
         double min_margin = 1e300;       // smallest (lower bound / tol) among the "continue" verdicts
         bool undecided = false, posted = false, chain_clean = true;   // chain = one enqueue of sweeps + verdicts
         bool resolved_on_device = false;
+        int full_evals = 0;                // tests of this solve evaluated in full, on the device or by the host
         if (c->cu_count == 0) {
             int cus = 0;
             HIP_TRY(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
@@ -562,8 +563,11 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
             // device-side resolution is enqueued behind the launch (settle the first inconclusive verdict
             // in place, go on sweeping from there) before the host looks at anything.  It costs three
             // near-empty launches when it turns out not to be needed.
+            // As many rounds as the previous solve had full evaluations (tests come close on several sweeps
+            // in a row where the spectrum of the moves is flat), four at most; a round that finds nothing to
+            // settle is three near-empty launches.
             const int dev_rounds = (start == 0 && persistent && c->device_resolve && screen_resolve_covers(r) &&
-                                    c->screen_last_undecided) ? 1 : 0;
+                                    c->screen_last_undecided) ? std::min(4, std::max(1, c->screen_last_evals)) : 0;
             const bool ahead = after && (rb & 3) == 0 && (start > 0 || !c->screen_last_undecided || dev_rounds > 0);
             posted = false;
             if (ahead && behind_sweeps) ONMF_TRY((*behind_sweeps)());
@@ -619,6 +623,7 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
                 const int nres = reinterpret_cast<const int*>(rec)[4 * SCREEN_MAX_SWEEPS + 1];
                 if (nres > 0) {
                     c->n_device_resolves += nres;
+                    full_evals += nres;
                     resolved_on_device = true;
                 }
             }
@@ -678,6 +683,7 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
                 }
                 double dist = nan;                        // bounds straddle tol: evaluate in full
                 undecided = true;
+                ++full_evals;
                 chain_clean = false;
                 // With several sweeps to go, both halves of the test are evaluated even where the cheap
                 // one would do: the exact sigma_max(H) they give makes the bounds of the sweeps that
@@ -712,6 +718,7 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
         // the next solve refreshes its probes if these left the bounds undecided or close to it
         c->screen_refresh_due = undecided || resolved_on_device || min_margin < 1.5;
         c->screen_last_undecided = undecided || resolved_on_device;
+        c->screen_last_evals = full_evals;
         if (cw_rows > 0 && done >= 1) {
             // ... or this one does, behind its last sweep and on that sweep's move: at once when the
             // bounds left a test undecided (or the probes are new), every fourth solve while the

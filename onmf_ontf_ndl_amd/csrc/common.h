@@ -85,6 +85,7 @@ struct onmf_ctx {
     bool screen_refresh_due = true; // the next screened solve runs a probe power step
     int screen_since_refresh = 0;   // solves since the probes' last power step (ranks that refresh behind the solve)
     bool screen_last_undecided = false;   // the last screened solve needed the host for a verdict
+    int screen_last_evals = 0;            // ... and this many of its tests were evaluated in full
     long long spin_limit = 200000000LL;   // bound of the sweeps' waits for each other, 100 MHz ticks (2 s)
     int persistent_sweeps = 1;      // all sweeps of a screened solve in one launch when the grid fits the chip
     int cu_count = 0;

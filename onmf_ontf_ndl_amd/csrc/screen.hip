@@ -450,30 +450,358 @@ __global__ __launch_bounds__(256) void screen_cw_finish_kernel(int r, float* bas
 //      the column index on the MFMA's k lanes, and one fragment serves as both operands);
 //   2. the parts go to a slab per workgroup; the workgroup that finishes last adds them in workgroup
 //      order (bitwise reproducible) into LDS, in double;
-//   3. two of its waves find the top eigenvalues by power iteration in double (Rayleigh quotients of
-//      a positive semi-definite matrix only grow; the iteration ends when they have stopped moving; the
-//      second eigenvalue of these matrices is 3-10 % of the first for H H^T and up to 3/4 for D D^T, i.e.
-//      5 to 60 steps of 64 multiply-adds per lane), one lane makes the reference's comparison and
-//      writes the verdict; for "continue" it reopens the loop exactly as the host would
-//      (screen_clear_flag_kernel): accumulator sets and counts of the next two sweeps cleared, the exact
-//      sigma_max(H_old) + sigma_max(D) as the next sweep's bound, flag 0, NEXT = i + 1.
-// An iteration that has not settled after RESOLVE_MAX_STEPS steps (a flat spectrum) leaves the record
-// as it is: the host then does it.
-// Measured (MI355X, c2 shape d=1024 r=64 b=8192): the kernel takes 79 us (13 power steps for D D^T) and a
-// step 0.47 ms with it against 0.44 ms with the host in the loop (whose part is about 125 us but overlaps
-// less badly than it looks under a profiler); at r = 16-25 the moves' Gram matrix has a flat spectrum
-// (second eigenvalue 0.7 of the first), the iteration needs 200-600 steps and a step gets slower (c1: 0.55
-// against 0.33 ms).  It is therefore OFF by default (ONMF_OPT_DEVICE_RESOLVE); what it needs to pay is a
-// Lanczos iteration in place of the power iteration and a Gram phase spread over more workgroups.
+//   3. two of its waves find the top eigenvalues in double by the host's own routine (Lanczos with full
+//      re-orthogonalisation, the tridiagonal's top eigenvalue by multisection: lanczos_top_wave), one lane
+//      makes the reference's comparison and writes the verdict; for "continue" it reopens the loop exactly
+//      as the host would (screen_clear_flag_kernel): accumulator sets and counts of the next two sweeps
+//      cleared, the exact sigma_max(H_old) + sigma_max(D) as the next sweep's bound, flag 0, NEXT = i + 1.
+// A matrix with a NaN leaves the record as it is: the host then does it.
+// Measured (MI355X, d=441 r=25 b=1000, where every solve stops early and three of its tests - the stop and the
+// two sweeps before it, 2 to 15 % above the threshold - need a full evaluation): the kernel takes 47 us, of
+// which 38 are step 3 (tridiagonalisation 32, multisection 6: a lone wave issues an instruction every seven or
+// eight clocks, and the algorithm is a chain of 23 dependent reflections) against about 100 us per evaluation
+// with the host in the loop; three rounds of (verdict kernel, this kernel, sweep launch) make a step 0.315 ms
+// against 0.29 ms with the host, which overlaps its evaluations with nothing but needs no extra launches.
+// It is therefore OFF by default (ONMF_OPT_DEVICE_RESOLVE).  What would make it pay: settling sweeps i and
+// i + 1 in one go (both moves are in the ring when the launch has stopped, and two waves are idle), i.e. two
+// rounds instead of three.  (A power iteration in step 3 was worse still: at r = 16-25 the moves' Gram
+// matrix has a second eigenvalue of 0.7 of the first and the iteration ran 200-600 steps.)
 // ---------------------------------------------------------------------------------------------
-constexpr int RESOLVE_MAX_STEPS = 200;
 constexpr int RESOLVE_COLS = 64;        // columns per staged tile
+#ifdef ONMF_RESOLVE_MARKS            // diagnostic build: stage times of the resolving workgroup (100 MHz ticks)
+#define RESOLVE_MARK(i) do { if (tid == 0) marks[i] = wall_clock64(); } while (0)
+#else
+#define RESOLVE_MARK(i) do {} while (0)
+#endif
 
-__device__ __forceinline__ double wave_sum_f64(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    return v;
+// wave-wide reductions on doubles: rows of 16 lanes by DPP rotations, the four row results by v_readlane
+// (every lane ends with the same bits; an LDS-crossbar shuffle chain costs five times as much)
+template <int CTRL>
+__device__ __forceinline__ double dpp_rot_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ double lane_f64(double v, int l) {          // l wave-uniform
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l),
+                            __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ __forceinline__ double wave_add_f64(double v) {
+    v += dpp_rot_f64<0x121>(v);
+    v += dpp_rot_f64<0x122>(v);
+    v += dpp_rot_f64<0x124>(v);
+    v += dpp_rot_f64<0x128>(v);
+    return (lane_f64(v, 0) + lane_f64(v, 16)) + (lane_f64(v, 32) + lane_f64(v, 48));
+}
+// two sums at once: the two dependent chains fill each other's latencies
+__device__ __forceinline__ void wave_add2_f64(double& a, double& b) {
+    a += dpp_rot_f64<0x121>(a);
+    b += dpp_rot_f64<0x121>(b);
+    a += dpp_rot_f64<0x122>(a);
+    b += dpp_rot_f64<0x122>(b);
+    a += dpp_rot_f64<0x124>(a);
+    b += dpp_rot_f64<0x124>(b);
+    a += dpp_rot_f64<0x128>(a);
+    b += dpp_rot_f64<0x128>(b);
+    a = (lane_f64(a, 0) + lane_f64(a, 16)) + (lane_f64(a, 32) + lane_f64(a, 48));
+    b = (lane_f64(b, 0) + lane_f64(b, 16)) + (lane_f64(b, 32) + lane_f64(b, 48));
+}
+// 1 / sqrt(x) and 1 / x for ordinary positive x (no denormals, no infinities): the hardware's estimate and two
+// Newton steps - a third of the dependent instructions of the correctly rounded library routines
+__device__ __forceinline__ double rsqrt_newton_f64(double x) {
+    double r = __builtin_amdgcn_rsq(x);
+    const double h = 0.5 * x;
+    r = r * fma(-h * r, r, 1.5);
+    r = r * fma(-h * r, r, 1.5);
+    return r;
+}
+__device__ __forceinline__ double rcp_newton_f64(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(r, fma(-x, r, 1.0), r);
+    r = fma(r, fma(-x, r, 1.0), r);
+    return r;
+}
+__device__ __forceinline__ double wave_max_f64(double v) {
+    v = fmax(v, dpp_rot_f64<0x121>(v));
+    v = fmax(v, dpp_rot_f64<0x122>(v));
+    v = fmax(v, dpp_rot_f64<0x124>(v));
+    v = fmax(v, dpp_rot_f64<0x128>(v));
+    return fmax(fmax(lane_f64(v, 0), lane_f64(v, 16)), fmax(lane_f64(v, 32), lane_f64(v, 48)));
+}
+// what one phase wrote to LDS is read by other lanes of the same wave in the next
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Top eigenvalue of the symmetric tridiagonal of order m <= 64 by multisection, one wave.  Lane i holds the
+// diagonal entry a_i and the entry b_i that couples rows i and i + 1 (what lanes >= m and b_{m-1} hold is not
+// used).  Every round the 64 lanes count the eigenvalues below 64 points that divide the bracket evenly - sign
+// changes in the sequence of characteristic polynomials of the leading blocks,
+//     p_i = (a_i - x) p_{i-1} - b_{i-1}^2 p_{i-2},
+// one multiply-add on the dependent chain per step, the coefficient pair of the step broadcast from LDS (coef:
+// 65 pairs of doubles, 16-byte aligned), the sign bits shifted into a word and counted every eighth step, where
+// the values are also rescaled so that they neither overflow nor vanish (the matrix is scaled to norm <= 1
+// first).  The recurrence runs in whole blocks of eight steps: the tridiagonal is padded with decoupled rows
+// far below the bracket, each of which adds one to every lane's count.  The bracket shrinks to the
+// sub-interval in which the count reaches the order - 65 times narrower per round, down to a relative width of
+// TRIDIAG_REL_WIDTH after eight.  `floor`: a known lower bound, or -inf.
+constexpr double TRIDIAG_REL_WIDTH = 1e-14;
+constexpr int TRIDIAG_COEF_DOUBLES = 2 * 65;
+__device__ double tridiag_top_lanes(double a_mine, double b_mine, int m, double floor, int lane, double* coef) {
+    if (m == 1) return lane_f64(a_mine, 0);
+    const double b_prev = __shfl_up(b_mine, 1);                    // lane i gets lane i - 1's
+    const double off = (lane > 0 && lane < m ? fabs(b_prev) : 0.0) + (lane + 1 < m ? fabs(b_mine) : 0.0);
+    const double a_in = lane < m ? a_mine : lane_f64(a_mine, 0);
+    const double off_in = lane < m ? off : 0.0;
+    double lo = -wave_max_f64(off_in - a_in);                       // Gershgorin
+    double hi = wave_max_f64(a_in + off_in);
+    // the top eigenvalue is at least the largest diagonal entry
+    lo = fmax(lo, wave_max_f64(a_in));
+    if (floor > lo && floor <= hi) lo = floor;
+    const double norm = fmax(fabs(lo), fabs(hi));
+    if (!(norm > 0.0)) return 0.0;
+    const double inv = 1.0 / norm;
+    lo *= inv;
+    hi *= inv;
+    const int steps = (m - 1 + 7) / 8 * 8;                          // i = 1 .. steps, rows m .. steps are padding
+    double2* cp = reinterpret_cast<double2*>(coef);
+    cp[lane] = (lane >= 1 && lane < m) ? make_double2(a_mine * inv, (b_prev * inv) * (b_prev * inv))
+                                       : make_double2(-10.0, 0.0);
+    if (lane == 0) cp[64] = make_double2(-10.0, 0.0);
+    const double a0 = lane_f64(a_mine, 0) * inv;
+    wave_lds_fence();
+    for (int round = 0; round < 16; ++round) {
+        const double width = hi - lo;
+        if (!(width > TRIDIAG_REL_WIDTH)) break;
+        const double x = lo + width * ((double)(lane + 1) * (1.0 / 65.0));
+        double p0 = 1.0, p1 = a0 - x;
+        unsigned w = (unsigned)__double2hiint(p1) >> 31;            // bit 0: the last value's sign
+        int cnt = (int)w;                                           // (p_0 = 1 is positive)
+        bool sawzero = p1 == 0.0;
+        for (int i0 = 1; i0 <= steps; i0 += 8) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const double2 c = cp[i0 + j];
+                const double p2 = fma(c.x - x, p1, -c.y * p0);
+                p0 = p1;
+                p1 = p2;
+                w = __builtin_amdgcn_alignbit(w, (unsigned)__double2hiint(p1), 31);      // (w << 1) | sign
+            }
+            cnt += __popc((w ^ (w >> 1)) & 0xFFu);
+            // (a value of exactly zero counts as either sign - its successor has the sign opposite to its
+            // predecessor's, so the count is the same - unless the coupling entry is zero too: then it stays
+            // zero to the end of the block and the careful form below takes over)
+            sawzero |= p1 == 0.0;
+            const double mag = fabs(p1);
+            const double sc = mag > 1e100 ? 1e-100 : (mag < 1e-100 ? 1e100 : 1.0);
+            p0 *= sc;
+            p1 *= sc;
+        }
+        int order = steps + 1;
+        if (__ballot(sawzero) != 0ull) {
+            // count again, zeros given the sign of their predecessor, without the padding
+            p0 = 1.0;
+            p1 = a0 - x;
+            bool neg = p1 < 0.0;
+            cnt = neg ? 1 : 0;
+            for (int i = 1; i < m; ++i) {
+                const double2 c = cp[i];
+                const double p2 = fma(c.x - x, p1, -c.y * p0);
+                p0 = p1;
+                p1 = p2;
+                const double mag = fabs(p1);
+                const double sc = mag > 1e100 ? 1e-100 : (mag < 1e-100 ? 1e100 : 1.0);
+                p0 *= sc;
+                p1 *= sc;
+                if (p1 != 0.0) {
+                    const bool n2 = p1 < 0.0;
+                    cnt += (n2 != neg) ? 1 : 0;
+                    neg = n2;
+                }
+            }
+            order = m;
+        }
+        // lanes below the top eigenvalue count fewer than the order: they form a prefix
+        const unsigned long long below = __ballot(cnt < order);
+        const int k = below == ~0ull ? 64 : __ffsll((long long)~below) - 1;
+        const double nlo = k > 0 ? lane_f64(x, k - 1) : lo;
+        const double nhi = k < 64 ? lane_f64(x, k) : hi;
+        if (nlo == lo && nhi == hi) break;              // down to neighbouring doubles
+        lo = nlo;
+        hi = nhi;
+    }
+    wave_lds_fence();
+    return 0.5 * (lo + hi) * norm;
+}
+// the same with the coefficients in LDS arrays
+__device__ double tridiag_top_wave(const double* a, const double* b, int m, double floor, int lane, double* coef) {
+    return tridiag_top_lanes(lane < m ? a[lane] : 0.0, lane + 1 < m ? b[lane] : 0.0, m, floor, lane, coef);
+}
+
+// Largest eigenvalue of the symmetric positive semi-definite n x n matrix M (doubles in LDS, rows RP apart),
+// one wave: Lanczos with full re-orthogonalisation (classical Gram-Schmidt, twice) and the tridiagonal's top
+// eigenvalue by multisection - the routine the host runs on the same matrices (host_eig.cpp), lane i
+// owning component i.  All n steps for n <= 32 (exact, whatever the spectrum: at r = 16-25 the moves'
+// Gram matrix has a second eigenvalue of 0.7 of the first, which a power iteration needs hundreds of steps
+// for); above, the run ends when the top Ritz value has stopped moving (looked at every fourth step).
+// work: the multisection's coefficient pairs, (n + 1) x LZ_PITCH doubles of Lanczos vectors, 64 + 64 + 64 + 64 doubles.
+constexpr int LZ_PITCH = 65;       // rows of the vector store one double more than a wave apart: lane l reading
+                                   // its own row meets no other lane's bank
+__device__ double lanczos_top_wave(const double* M, int n, int RP, double* work, int lane, int* ok) {
+    double* coef = work;               // (first: 16-byte aligned)
+    double* V = work + TRIDIAG_COEF_DOUBLES;
+    double* wb = V + (size_t)(n + 1) * LZ_PITCH;
+    double* cb = wb + 64;
+    double* al = cb + 64;
+    double* be = al + 64;
+    const bool act = lane < n;
+    *ok = 1;
+    double f = 0.0;
+    if (act)
+        for (int j = 0; j < n; ++j) f = fma(M[j * RP + lane], M[j * RP + lane], f);
+    const double fro = wave_add_f64(f);
+    if (!(fro > 0.0)) {
+        *ok = (fro == 0.0);
+        return 0.0;
+    }
+    if (n == 1) return M[0];
+    double v = act ? 1.0 + 0.5 * sin(12.9898 * (double)(lane + 1)) : 0.0;
+    v *= 1.0 / sqrt(wave_add_f64(v * v));
+    V[lane] = v;
+    wave_lds_fence();
+    const double ninf = -__builtin_inf();
+    double prev = -1.0;
+    int m = 0;
+    for (int j = 0; j < n; ++j) {
+        const double* vj = V + j * LZ_PITCH;
+        double w = 0.0;
+        if (act) {
+#pragma unroll 8
+            for (int i = 0; i < n; ++i) w = fma(M[i * RP + lane], vj[i], w);     // M symmetric: column = row
+        }
+        const double alpha = wave_add_f64(w * v);
+        for (int pass = 0; pass < 2; ++pass) {
+            wb[lane] = w;
+            wave_lds_fence();
+            double cl = 0.0;
+            if (lane <= j) {
+#pragma unroll 8
+                for (int i = 0; i < n; ++i) cl = fma(V[lane * LZ_PITCH + i], wb[i], cl);
+            }
+            cb[lane] = cl;
+            wave_lds_fence();
+            if (act) {
+#pragma unroll 8
+                for (int l = 0; l <= j; ++l) w = fma(-cb[l], V[l * LZ_PITCH + lane], w);
+            }
+            wave_lds_fence();
+        }
+        const double bn = sqrt(wave_add_f64(w * w));
+        if (lane == 0) al[j] = alpha;
+        m = j + 1;
+        wave_lds_fence();
+        if (bn <= 1e-14 * sqrt(fro) || m == n) break;   // invariant subspace, or all n steps: exact
+        if (n > 32 && m >= 8 && (m & 3) == 0) {
+            const double theta = tridiag_top_wave(al, be, m, prev > 0.0 ? prev : ninf, lane, coef);
+            if (prev > 0.0 && theta - prev <= 1e-13 * theta) return theta;
+            prev = theta;
+        }
+        if (lane == 0) be[j] = bn;
+        v = w * (1.0 / bn);
+        V[(j + 1) * LZ_PITCH + lane] = v;
+        wave_lds_fence();
+    }
+    return tridiag_top_wave(al, be, m, prev > 0.0 ? prev : ninf, lane, coef);
+}
+
+// The same value for small matrices (n <= 32) by Householder tridiagonalisation, one wave: n - 2 reflections,
+// each a product with the trailing matrix, two wave-wide sums and a symmetric rank-two update - exact after a
+// fixed number of operations whatever the spectrum, and a fraction of what the Lanczos run with its
+// re-orthogonalisation costs at these sizes.  Lane j works on column j of the matrix, which stays in LDS (M: n x n
+// doubles, rows RP apart, overwritten); the entries of the reflector and of the update's vector are broadcast
+// from LDS.  A lone wave issues an instruction every seven or eight clocks and fetches straight-line code
+// slower than it runs it (a version unrolled over the reflections, matrix in registers, took longer for its
+// instruction fetches than this one for its LDS round trips), so: short loops, few instructions.
+// work: the multisection's coefficient pairs, 64 doubles, 64 pairs of doubles (16-byte aligned).
+__device__ double householder_top_wave(double* M, int n, int RP, double* work, int lane, int* ok) {
+    double* coef = work;
+    double* xs = work + TRIDIAG_COEF_DOUBLES;
+    double2* uq = reinterpret_cast<double2*>(xs + 64);
+    *ok = 1;
+    double f = 0.0;
+    if (lane < n) {
+#pragma unroll 4
+        for (int j = 0; j < n; ++j) f = fma(M[j * RP + lane], M[j * RP + lane], f);
+    }
+    const double fro = wave_add_f64(f);
+    if (!(fro > 0.0)) {
+        *ok = (fro == 0.0);
+        return 0.0;
+    }
+    if (n == 1) return M[0];
+    double a_mine = 0.0, b_mine = 0.0;                              // lane k: a_k and b_k of the tridiagonal
+    double* col = M + lane;                                         // column `lane` = row `lane` (symmetric)
+    for (int k = 0; k + 1 < n; ++k) {
+        const bool act = lane > k && lane < n;
+        const double mk = lane < n ? col[k * RP] : 0.0;
+        if (lane == k) a_mine = mk;
+        const double x = act ? mk : 0.0;
+        double bk;
+        if (k + 2 < n) {
+            xs[lane] = x;
+            wave_lds_fence();
+            const double x0 = xs[k + 1];
+            bk = x0;
+            // y = S x over the trailing rows, before the reflector's scale is known: S u = S x - alpha S e_{k+1}
+            // and u^T S u = x^T S x - 2 alpha (S x)_{k+1} + alpha^2 S_{k+1,k+1}, so both sums of the step (|x|^2
+            // and x^T S x) travel through the wave together
+            double y0 = 0.0, y1 = 0.0, mk1 = 0.0;
+            if (act) {
+                mk1 = col[(k + 1) * RP];
+                y0 = mk1 * x0;
+                int i = k + 2;
+                for (; i + 1 < n; i += 2) {
+                    y1 = fma(col[i * RP], xs[i], y1);
+                    y0 = fma(col[(i + 1) * RP], xs[i + 1], y0);
+                }
+                if (i < n) y1 = fma(col[i * RP], xs[i], y1);
+            }
+            const double y = y0 + y1;
+            double nx2 = x * x, xy = x * y;
+            wave_add2_f64(nx2, xy);
+            if (nx2 > x0 * x0) {                                    // something below the sub-diagonal: reflect
+                const double nx = nx2 * rsqrt_newton_f64(nx2);
+                const double alpha = x0 > 0.0 ? -nx : nx;
+                const double tau = rcp_newton_f64(fma(nx, fabs(x0), nx2));     // 2 / |u|^2,  u = x - alpha e_{k+1}
+                const double usu = fma(alpha * alpha, lane_f64(mk1, k + 1), fma(-2.0 * alpha, lane_f64(y, k + 1), xy));
+                const double u = (lane == k + 1) ? x - alpha : x;
+                const double pj = tau * fma(-alpha, mk1, y);        // tau S u  (lane j: S_{j,k+1} = S_{k+1,j})
+                const double q = fma(-0.5 * tau * tau * usu, u, pj);
+                uq[lane] = make_double2(-u, -q);
+                wave_lds_fence();
+                if (act) {
+#pragma unroll 4
+                    for (int i = k + 1; i < n; ++i) {
+                        const double2 c = uq[i];
+                        col[i * RP] = fma(c.x, q, fma(c.y, u, col[i * RP]));
+                    }
+                }
+                wave_lds_fence();
+                bk = alpha;
+            }
+        } else {
+            bk = lane_f64(x, k + 1);
+            const double last = lane_f64(lane < n ? col[(k + 1) * RP] : 0.0, k + 1);
+            if (lane == k + 1) a_mine = last;
+        }
+        if (lane == k) b_mine = bk;
+    }
+    return tridiag_top_lanes(a_mine, b_mine, n, -__builtin_inf(), lane, coef);
+}
+
+// work space of one wave's eigenvalue run, in doubles (even: its (u, q) pairs are read 16 bytes at a time)
+constexpr int eig_work_doubles(int RP) { return (TRIDIAG_COEF_DOUBLES + (RP + 1) * LZ_PITCH + 4 * 64 + 1) & ~1; }
 
 template <int NB>
 __global__ __launch_bounds__(256) void screen_resolve_kernel(float* base, int r, int b, const float* hb0,
@@ -483,6 +811,7 @@ __global__ __launch_bounds__(256) void screen_resolve_kernel(float* base, int r,
     constexpr int PITCH = RP + 4;                       // staged tiles are [column][row], rows padded
     constexpr int NPAIR = NB * NB;                      // 16 x 16 output blocks of one Gram matrix
     constexpr int PER_WAVE = (NPAIR + 3) / 4;
+    constexpr int EIG_WORK = eig_work_doubles(RP);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* Dt = lds;                                    // [RESOLVE_COLS][PITCH]
     float* Ht = lds + RESOLVE_COLS * PITCH;
@@ -492,6 +821,10 @@ __global__ __launch_bounds__(256) void screen_resolve_kernel(float* base, int r,
     int* ibase = reinterpret_cast<int*>(base);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c16 = lane & 15, g4 = lane >> 4;
+#ifdef ONMF_RESOLVE_MARKS
+    long long marks[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    RESOLVE_MARK(0);
     if (tid == 0) {
         int sel = -1;
         if (ibase[ScreenLayout::FLAG] != 0) {           // the loop was ended: by a stop, or for want of a verdict
@@ -513,24 +846,37 @@ __global__ __launch_bounds__(256) void screen_resolve_kernel(float* base, int r,
     const float* Hnew = ((isel + 1) % 3 == 0) ? hb0 : ((isel + 1) % 3 == 1) ? hb1 : hb2;
     const float* Hold = (isel % 3 == 0) ? hb0 : (isel % 3 == 1) ? hb1 : hb2;
 
+    RESOLVE_MARK(1);
     // ---- 1. this workgroup's part of the two Gram matrices ----
     f32x4 accD[PER_WAVE], accH[PER_WAVE];
 #pragma unroll
     for (int p = 0; p < PER_WAVE; ++p) accD[p] = accH[p] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int col_lo = blockIdx.x * cols_per_wg, col_hi = min(b, col_lo + cols_per_wg);
+    // (a tile's loads are all issued before the first is used, and the next tile's before this one's products:
+    // one round trip to memory per tile, not one per element)
+    constexpr int PER = RP * RESOLVE_COLS / 256;        // elements of a tile per thread and matrix
+    float hn[PER], ho[PER];
+    auto fetch = [&](int c0) {
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int e = tid + 256 * q;
+            const int row = e / RESOLVE_COLS, col = c0 + e % RESOLVE_COLS;   // consecutive threads: consecutive columns
+            const bool in = row < r && col < col_hi;
+            hn[q] = in ? Hnew[(size_t)row * b + col] : 0.f;
+            ho[q] = in ? Hold[(size_t)row * b + col] : 0.f;
+        }
+    };
+    if (col_lo < col_hi) fetch(col_lo);
     for (int c0 = col_lo; c0 < col_hi; c0 += RESOLVE_COLS) {
         __syncthreads();                                // the previous tile's readers are done
-        for (int e = tid; e < RP * RESOLVE_COLS; e += 256) {
-            const int row = e / RESOLVE_COLS, cc = e % RESOLVE_COLS;     // consecutive threads: consecutive columns
-            const int col = c0 + cc;
-            float hn = 0.f, ho = 0.f;
-            if (row < r && col < col_hi) {
-                hn = Hnew[(size_t)row * b + col];
-                ho = Hold[(size_t)row * b + col];
-            }
-            Dt[cc * PITCH + row] = hn - ho;
-            Ht[cc * PITCH + row] = ho;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int e = tid + 256 * q;
+            const int row = e / RESOLVE_COLS, cc = e % RESOLVE_COLS;
+            Dt[cc * PITCH + row] = hn[q] - ho[q];
+            Ht[cc * PITCH + row] = ho[q];
         }
+        if (c0 + RESOLVE_COLS < col_hi) fetch(c0 + RESOLVE_COLS);
         __syncthreads();
 #pragma unroll
         for (int p = 0; p < PER_WAVE; ++p) {
@@ -548,6 +894,7 @@ __global__ __launch_bounds__(256) void screen_resolve_kernel(float* base, int r,
             }
         }
     }
+    RESOLVE_MARK(2);
     // ---- 2. slab of this workgroup, then the last one adds them all ----
     float* mine = slab + (size_t)blockIdx.x * 2 * RP * RP;
 #pragma unroll
@@ -572,6 +919,7 @@ __global__ __launch_bounds__(256) void screen_resolve_kernel(float* base, int r,
     __syncthreads();
     if (!last_s) return;
     __threadfence();
+    RESOLVE_MARK(3);
     // (the staging tiles are dead: the double-precision matrices take their place)
     double* S = reinterpret_cast<double*>(lds);         // [2][RP * RP]
     // (the other workgroups released their slabs before they counted themselves in, and the fence above
@@ -598,42 +946,21 @@ __global__ __launch_bounds__(256) void screen_resolve_kernel(float* base, int r,
         }
     }
     __syncthreads();
+    RESOLVE_MARK(4);
     // ---- 3. top eigenvalues: wave 0 of D D^T, wave 1 of H H^T ----
     if (wave < 2) {
-        const double* M = S + wave * RP * RP;
-        double* vb = S + 2 * RP * RP + wave * 64;       // this wave's copy of the iterate
-        const bool act = lane < RP;
-        double v = act ? 1.0 + 0.5 * sin(12.9898 * (double)(lane + 1)) : 0.0;
-        double nv = wave_sum_f64(v * v);
-        v *= 1.0 / sqrt(nv);
-        double theta = 0.0, prev = -1.0;
-        int calm = 0, ok = 0;
-        for (int it = 0; it < RESOLVE_MAX_STEPS; ++it) {
-            vb[lane] = v;
-            __builtin_amdgcn_wave_barrier();
-            double y = 0.0;
-            if (act) {
-#pragma unroll 8
-                for (int j = 0; j < RP; ++j) y = fma(M[j * RP + lane], vb[j], y);    // M symmetric: column = row
-            }
-            __builtin_amdgcn_wave_barrier();
-            theta = wave_sum_f64(v * y);                // Rayleigh quotient of the unit vector v
-            const double ny = wave_sum_f64(y * y);
-            if (!(ny > 0.0)) { ok = (ny == 0.0); theta = 0.0; break; }     // zero matrix (or NaN: not ok)
-            v = y * (1.0 / sqrt(ny));
-            if (prev >= 0.0 && theta - prev <= 1e-15 * theta) {
-                if (++calm >= 2) { ok = 1; break; }
-            } else {
-                calm = 0;
-            }
-            prev = theta;
-        }
+        double* work = S + 2 * RP * RP + (size_t)wave * EIG_WORK;
+        int ok = 0;
+        double* M = S + wave * RP * RP;
+        const double theta = r <= 32 ? householder_top_wave(M, r, RP, work, lane, &ok)
+                                     : lanczos_top_wave(M, r, RP, work, lane, &ok);
         if (lane == 0) {
             lam_s[wave] = theta;
             ok_s[wave] = ok;
         }
     }
     __syncthreads();
+    RESOLVE_MARK(5);
     const double lD = lam_s[0], lH = lam_s[1];
     const bool settled = ok_s[0] && ok_s[1] && lH > 0.0 && lD >= 0.0;     // else: left to the host
     const double dist = settled ? sqrt(lD) / sqrt(lH) : 0.0;
@@ -646,6 +973,11 @@ __global__ __launch_bounds__(256) void screen_resolve_kernel(float* base, int r,
         }
     }
     __syncthreads();
+#ifdef ONMF_RESOLVE_MARKS
+    if (tid == 0)
+        printf("resolve marks (10 ns): find %lld, gram %lld, slab+count %lld, add slabs %lld, eig %lld\n", marks[1] - marks[0],
+               marks[2] - marks[1], marks[3] - marks[2], marks[4] - marks[3], marks[5] - marks[4]);
+#endif
     if (tid == 0) {
         ibase[ScreenLayout::RCNT] = 0;
         if (settled) {
@@ -671,13 +1003,14 @@ __global__ __launch_bounds__(256) void screen_resolve_kernel(float* base, int r,
 template <int NB>
 int run_resolve(onmf_ctx* c, float* base, int r, int b, float* const* hb, int sub_iter, float tol, hipStream_t s) {
     constexpr int RP = 16 * NB;
-    // columns per workgroup: at least 256 and a multiple of the tile, at most 64 workgroups
-    int cols = std::max(256, (b + 63) / 64);
+    // columns per workgroup: a multiple of the tile, at most 32 workgroups (the one that finishes last adds
+    // up all their slabs)
+    int cols = std::max(RESOLVE_COLS, (b + 31) / 32);
     cols = (cols + RESOLVE_COLS - 1) / RESOLVE_COLS * RESOLVE_COLS;
     const int nwg = (b + cols - 1) / cols;
     ONMF_TRY(onmf_reserve(c, c->rslab, (size_t)nwg * 2 * RP * RP * sizeof(float), "verdict resolution slabs"));
     const size_t tiles = (size_t)2 * RESOLVE_COLS * (RP + 4) * sizeof(float);
-    const size_t mats = ((size_t)2 * RP * RP + 2 * 64) * sizeof(double);
+    const size_t mats = ((size_t)2 * RP * RP + 2 * eig_work_doubles(RP)) * sizeof(double);
     const size_t lds = std::max(tiles, mats);
     static LdsLimit lim;
     ONMF_TRY(onmf_raise_lds_limit(c, lim, (const void*)screen_resolve_kernel<NB>, lds));
