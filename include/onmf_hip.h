@@ -373,14 +373,18 @@ double onmf_host_lambda_max(const float* S_host, int n);
  *   ONMF_OPT_PERSISTENT_SWEEPS != 0 (default): with the screened stopping test, run all sweeps of
  *                          a solve in one launch when its grid (one workgroup per 256 columns)
  *                          fits the chip's CUs; 0: one launch per sweep.
- *   ONMF_OPT_DEVICE_RESOLVE != 0: for r <= 64, when the previous solve needed full evaluations of the
- *                          stopping test, the next one-launch solve carries as many rounds (four at most) of
- *                          device-side resolution (both Gram matrices and their top eigenvalues computed on
- *                          the GPU - Householder tridiagonalisation for r <= 32, Lanczos above, multisection
- *                          - the sweeps continued from there) so that the host is not in the loop; 0
- *                          (default: a round costs 47 us and three launches at r = 25, which does not beat
- *                          the host's round trip): the host evaluates every inconclusive test.  Same sweep
- *                          counts and codes either way.
+ *   ONMF_OPT_DEVICE_RESOLVE  where the bounds cannot decide a stopping test, it is evaluated in full: by the host
+ *                          (two launches, a copy, two eigenvalue problems, a new sweep launch: about 60 us per
+ *                          test at r = 25), or by a kernel enqueued ahead of time behind a one-launch solve - both
+ *                          Gram matrices and their top eigenvalues on the GPU (Householder tridiagonalisation
+ *                          for r <= 32, Lanczos above, multisection), the sweeps continued from there - as
+ *                          many rounds (four at most) as the previous solve needed.  For r <= 32 a round settles
+ *                          the inconclusive sweep AND the one after it (whose move is still in the work
+ *                          buffers).  < 0 (default): device rounds for r <= 32 behind a solve that stopped
+ *                          early and needed a full evaluation (measured: 0.23 against 0.30 ms per step at d = 441,
+ *                          r = 25, b = 1000); 0: the host evaluates every such test; > 0: device rounds for every
+ *                          r <= 64 behind any solve that needed a full evaluation (at r = 64 a round costs
+ *                          about what the host's does).  Same sweep counts and codes in every setting.
  *   ONMF_OPT_LARS_SLOTS    onmf_sparse_code_lars keeps, per column, the inverse Gram matrix of the active atoms in
  *                          LDS.  Room for all r atoms lets only a few wavefronts be resident per CU, so a call
  *                          sizes its launch by how many columns of the PREVIOUS call needed more than 16, 32,

@@ -507,7 +507,7 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
         double min_margin = 1e300;       // smallest (lower bound / tol) among the "continue" verdicts
         bool undecided = false, posted = false, chain_clean = true;   // chain = one enqueue of sweeps + verdicts
         bool resolved_on_device = false;
-        int full_evals = 0;                // tests of this solve evaluated in full, on the device or by the host
+        int full_evals = 0;                // full evaluations of this solve: rounds on the device + tests on the host
         if (c->cu_count == 0) {
             int cus = 0;
             HIP_TRY(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
@@ -566,8 +566,15 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
             // As many rounds as the previous solve had full evaluations (tests come close on several sweeps
             // in a row where the spectrum of the moves is flat), four at most; a round that finds nothing to
             // settle is three near-empty launches.
-            const int dev_rounds = (start == 0 && persistent && c->device_resolve && screen_resolve_covers(r) &&
-                                    c->screen_last_undecided) ? std::min(4, std::max(1, c->screen_last_evals)) : 0;
+            // By default (ONMF_OPT_DEVICE_RESOLVE < 0) only where it was measured to pay: r <= 32, where a round
+            // settles two sweeps, and behind a solve that stopped early - such a solve needs a full evaluation
+            // at its stop whatever the probes are like (no upper bound is tight enough to end the loop), while
+            // one that ran all its sweeps only needed one because the lower bounds were loose, which the
+            // probe refresh behind it repairs.
+            const bool dev_on = c->device_resolve > 0 ? screen_resolve_covers(r)
+                                                      : (c->device_resolve < 0 && r <= 32 && c->screen_last_stopped_early);
+            const int dev_rounds = (start == 0 && persistent && dev_on && c->screen_last_undecided)
+                                       ? std::min(4, std::max(1, c->screen_last_evals)) : 0;
             const bool ahead = after && (rb & 3) == 0 && (start > 0 || !c->screen_last_undecided || dev_rounds > 0);
             posted = false;
             if (ahead && behind_sweeps) ONMF_TRY((*behind_sweeps)());
@@ -600,7 +607,7 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
                 ONMF_TRY((*after)());
                 posted = true;
                 const bool start_intact = H0 == nullptr || (H0 != buf[0] && H0 != buf[1] && H0 != buf[2]);
-                if (defer_redo && start == 0 && dev_rounds == 0 && start_intact && !second_try) {
+                if (defer_redo && start == 0 && start_intact && !second_try) {
                     // not waited for: the next entry point on this context settles it
                     PendingSolve& p = c->pend;
                     p.active = true;
@@ -609,6 +616,7 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
                     p.H = H;
                     for (int q = 0; q < 3; ++q) p.buf[q] = buf[q];
                     p.probes_new = probes_new;
+                    p.dev_rounds = dev_rounds;
                     p.s = s;
                     p.redo_after = *defer_redo;
                     if (after_valid) *after_valid = true;
@@ -623,7 +631,8 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
                 const int nres = reinterpret_cast<const int*>(rec)[4 * SCREEN_MAX_SWEEPS + 1];
                 if (nres > 0) {
                     c->n_device_resolves += nres;
-                    full_evals += nres;
+                    // (rounds, not tests: a round may settle two sweeps)
+                    full_evals += reinterpret_cast<const int*>(rec)[4 * SCREEN_MAX_SWEEPS + 3];
                     resolved_on_device = true;
                 }
             }
@@ -719,6 +728,7 @@ static int sparse_code_impl(onmf_ctx* c, int d, int r, int b, const float* X, in
         c->screen_refresh_due = undecided || resolved_on_device || min_margin < 1.5;
         c->screen_last_undecided = undecided || resolved_on_device;
         c->screen_last_evals = full_evals;
+        c->screen_last_stopped_early = done < sub_iter;
         if (cw_rows > 0 && done >= 1) {
             // ... or this one does, behind its last sweep and on that sweep's move: at once when the
             // bounds left a test undecided (or the probes are new), every fourth solve while the
@@ -847,11 +857,17 @@ int onmf_settle_pending(onmf_ctx* c) {
     }
     float* base = (float*)c->screen.p;
     if (clean) {
-        c->screen_refresh_due = min_margin < 1.5;
-        c->screen_last_undecided = false;
+        // (tests settled by the device rounds that were enqueued behind the sweeps read as conclusive here)
+        const int* words = reinterpret_cast<const int*>(rec) + 4 * SCREEN_MAX_SWEEPS;
+        const int nres = p.dev_rounds > 0 ? words[1] : 0, rounds = p.dev_rounds > 0 ? words[3] : 0;
+        c->n_device_resolves += nres;
+        c->screen_refresh_due = nres > 0 || min_margin < 1.5;
+        c->screen_last_undecided = nres > 0;
+        c->screen_last_evals = rounds;
+        c->screen_last_stopped_early = done < p.sub_iter;
         if (p.cw_rows > 0 && done >= 1) {
             ++c->screen_since_refresh;
-            if (p.probes_new || (min_margin < 1.5 && c->screen_since_refresh >= 4)) {
+            if (nres > 0 || p.probes_new || (min_margin < 1.5 && c->screen_since_refresh >= 4)) {
                 ONMF_TRY(launch_screen_refresh(c, base, p.r, p.b, p.buf[done % 3], p.buf[(done + 2) % 3], p.s));
                 c->screen_since_refresh = 0;
             }

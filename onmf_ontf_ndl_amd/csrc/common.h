@@ -35,6 +35,7 @@ struct PendingSolve {
     float* H = nullptr;
     float* buf[3] = {nullptr, nullptr, nullptr};
     bool probes_new = false;
+    int dev_rounds = 0;                     // rounds of device-side evaluation enqueued behind the sweeps
     hipStream_t s = nullptr;
     std::function<int()> redo_after;        // what consumed the code (the step's aggregate products), by value
 };
@@ -64,7 +65,7 @@ struct onmf_ctx {
     DevBuf dbuf;                    // H - H_prev for the exact stopping test (r x b)
     DevBuf gstack;                  // small r: [H - H_prev ; H_prev] stacked (2r x b), one product for both Grams
     DevBuf rslab;                   // device-side verdict resolution: per-workgroup partial Gram matrices
-    int device_resolve = 0;         // settle inconclusive verdicts on the device (r <= 64; opt-in: see screen.hip)
+    int device_resolve = -1;        // settle inconclusive verdicts on the device: < 0 where it pays (see api.hip), 0 never, > 0 for every r <= 64
     long long n_device_resolves = 0;
     DevBuf screen;                  // stopping-test screen state (ScreenLayout)
     DevBuf slab_side;               // split-K slabs of products issued on the side stream
@@ -86,6 +87,7 @@ struct onmf_ctx {
     int screen_since_refresh = 0;   // solves since the probes' last power step (ranks that refresh behind the solve)
     bool screen_last_undecided = false;   // the last screened solve needed the host for a verdict
     int screen_last_evals = 0;            // ... and this many of its tests were evaluated in full
+    bool screen_last_stopped_early = false;   // the last screened solve ended before its last sweep
     long long spin_limit = 200000000LL;   // bound of the sweeps' waits for each other, 100 MHz ticks (2 s)
     int persistent_sweeps = 1;      // all sweeps of a screened solve in one launch when the grid fits the chip
     int cu_count = 0;
@@ -338,6 +340,7 @@ struct ScreenLayout {           // offsets in floats into ctx->screen
     static constexpr int NEXT = REC + 4 * SCREEN_MAX_SWEEPS;       // first sweep of the launch enqueued behind it
     static constexpr int NRES = NEXT + 1;                          // verdicts resolved on the device in this solve
     static constexpr int RCNT = NEXT + 2;                          // its workgroups done with their partial Grams
+    static constexpr int RNDS = NEXT + 3;                          // launches of it that settled something in this solve
     static constexpr int CWY = NEXT + 4;                           // 256 doubles: H H^T v
     static constexpr int TOTAL = CWY + 512;
 };

@@ -446,7 +446,7 @@ __global__ __launch_bounds__(256) void screen_cw_finish_kernel(int r, float* bas
 //   1. every workgroup finds the sweep i to settle in the verdict records (the first inconclusive one
 //      with only "continue" before it; none: nothing to do), reads its columns of H_new (ring buffer
 //      (i+1) % 3) and H_old (i % 3), stages D and H_old transposed in LDS and accumulates its part of the
-//      two RP x RP Gram matrices on the matrix cores (contraction over columns: the transposed tile puts
+//      two (four: below) RP x RP Gram matrices on the matrix cores (contraction over columns: the transposed tile puts
 //      the column index on the MFMA's k lanes, and one fragment serves as both operands);
 //   2. the parts go to a slab per workgroup; the workgroup that finishes last adds them in workgroup
 //      order (bitwise reproducible) into LDS, in double;
@@ -456,16 +456,18 @@ __global__ __launch_bounds__(256) void screen_cw_finish_kernel(int r, float* bas
 //      as the host would (screen_clear_flag_kernel): accumulator sets and counts of the next two sweeps
 //      cleared, the exact sigma_max(H_old) + sigma_max(D) as the next sweep's bound, flag 0, NEXT = i + 1.
 // A matrix with a NaN leaves the record as it is: the host then does it.
+// For r <= 32 the kernel settles sweep i + 1 in the same go when sweep i's test says "go on": the launch that
+// stopped had run sweep i + 1 ahead of the verdict, so its move is in the ring of three buffers too, and the
+// two waves that would idle through step 3 take its two matrices; the loop then goes on at sweep i + 2.
 // Measured (MI355X, d=441 r=25 b=1000, where every solve stops early and three of its tests - the stop and the
 // two sweeps before it, 2 to 15 % above the threshold - need a full evaluation): the kernel takes 47 us, of
 // which 38 are step 3 (tridiagonalisation 32, multisection 6: a lone wave issues an instruction every seven or
-// eight clocks, and the algorithm is a chain of 23 dependent reflections) against about 100 us per evaluation
-// with the host in the loop; three rounds of (verdict kernel, this kernel, sweep launch) make a step 0.315 ms
-// against 0.29 ms with the host, which overlaps its evaluations with nothing but needs no extra launches.
-// It is therefore OFF by default (ONMF_OPT_DEVICE_RESOLVE).  What would make it pay: settling sweeps i and
-// i + 1 in one go (both moves are in the ring when the launch has stopped, and two waves are idle), i.e. two
-// rounds instead of three.  (A power iteration in step 3 was worse still: at r = 16-25 the moves' Gram
-// matrix has a second eigenvalue of 0.7 of the first and the iteration ran 200-600 steps.)
+// eight clocks, and the algorithm is a chain of 23 dependent reflections), against about 60 us per test with
+// the host in the loop.  Two rounds of (verdict kernel, this kernel, sweep launch) per solve: a step takes
+// 0.23 ms against 0.30 with the host (0.315 with one sweep per round, i.e. three rounds).  At r = 64 (Lanczos,
+// one sweep per round) a round costs about what the host's evaluation does.  Hence the default of
+// ONMF_OPT_DEVICE_RESOLVE (api.hip).  (A power iteration in step 3 was far worse at small r: the moves' Gram
+// matrix has a second eigenvalue of 0.7 of the first there and the iteration ran 200-600 steps.)
 // ---------------------------------------------------------------------------------------------
 constexpr int RESOLVE_COLS = 64;        // columns per staged tile
 #ifdef ONMF_RESOLVE_MARKS            // diagnostic build: stage times of the resolving workgroup (100 MHz ticks)
@@ -812,12 +814,15 @@ __global__ __launch_bounds__(256) void screen_resolve_kernel(float* base, int r,
     constexpr int NPAIR = NB * NB;                      // 16 x 16 output blocks of one Gram matrix
     constexpr int PER_WAVE = (NPAIR + 3) / 4;
     constexpr int EIG_WORK = eig_work_doubles(RP);
+    // r <= 32: the sweep after the inconclusive one is settled in the same go (its move is in the ring too: the
+    // stopped launch ran it ahead of the verdict), by the two waves that would otherwise idle through step 3
+    constexpr bool TWO = NB <= 2;
+    constexpr int NM = TWO ? 4 : 2;                     // matrices: D_i D_i^T, H_i H_i^T (, D_{i+1} .., H_{i+1} ..)
+    constexpr int TILE = RESOLVE_COLS * PITCH;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* Dt = lds;                                    // [RESOLVE_COLS][PITCH]
-    float* Ht = lds + RESOLVE_COLS * PITCH;
     __shared__ int sel_s, last_s;
-    __shared__ double lam_s[2];
-    __shared__ int ok_s[2];
+    __shared__ double lam_s[4];
+    __shared__ int ok_s[4];
     int* ibase = reinterpret_cast<int*>(base);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c16 = lane & 15, g4 = lane >> 4;
@@ -843,27 +848,34 @@ __global__ __launch_bounds__(256) void screen_resolve_kernel(float* base, int r,
         if (blockIdx.x == 0 && tid == 0) ibase[ScreenLayout::NEXT] = sub_iter;    // nothing follows
         return;
     }
-    const float* Hnew = ((isel + 1) % 3 == 0) ? hb0 : ((isel + 1) % 3 == 1) ? hb1 : hb2;
-    const float* Hold = (isel % 3 == 0) ? hb0 : (isel % 3 == 1) ? hb1 : hb2;
+    const bool two = TWO && isel + 2 < sub_iter;        // (sweep isel + 1 ran, and its test decides something)
+    const int nm = two ? 4 : 2;
+    auto ring = [&](int k) { return (k % 3 == 0) ? hb0 : (k % 3 == 1) ? hb1 : hb2; };
+    const float* H0p = ring(isel);                      // code before sweep isel, after it, after the next
+    const float* H1p = ring(isel + 1);
+    const float* H2p = ring(isel + 2);
 
     RESOLVE_MARK(1);
-    // ---- 1. this workgroup's part of the two Gram matrices ----
-    f32x4 accD[PER_WAVE], accH[PER_WAVE];
+    // ---- 1. this workgroup's part of the Gram matrices ----
+    f32x4 acc[NM][PER_WAVE];
 #pragma unroll
-    for (int p = 0; p < PER_WAVE; ++p) accD[p] = accH[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < NM; ++m)
+#pragma unroll
+        for (int p = 0; p < PER_WAVE; ++p) acc[m][p] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int col_lo = blockIdx.x * cols_per_wg, col_hi = min(b, col_lo + cols_per_wg);
     // (a tile's loads are all issued before the first is used, and the next tile's before this one's products:
     // one round trip to memory per tile, not one per element)
     constexpr int PER = RP * RESOLVE_COLS / 256;        // elements of a tile per thread and matrix
-    float hn[PER], ho[PER];
+    float h0[PER], h1[PER], h2[TWO ? PER : 1];
     auto fetch = [&](int c0) {
 #pragma unroll
         for (int q = 0; q < PER; ++q) {
             const int e = tid + 256 * q;
             const int row = e / RESOLVE_COLS, col = c0 + e % RESOLVE_COLS;   // consecutive threads: consecutive columns
             const bool in = row < r && col < col_hi;
-            hn[q] = in ? Hnew[(size_t)row * b + col] : 0.f;
-            ho[q] = in ? Hold[(size_t)row * b + col] : 0.f;
+            h0[q] = in ? H0p[(size_t)row * b + col] : 0.f;
+            h1[q] = in ? H1p[(size_t)row * b + col] : 0.f;
+            if constexpr (TWO) h2[q] = (in && two) ? H2p[(size_t)row * b + col] : 0.f;
         }
     };
     if (col_lo < col_hi) fetch(col_lo);
@@ -873,40 +885,51 @@ __global__ __launch_bounds__(256) void screen_resolve_kernel(float* base, int r,
         for (int q = 0; q < PER; ++q) {
             const int e = tid + 256 * q;
             const int row = e / RESOLVE_COLS, cc = e % RESOLVE_COLS;
-            Dt[cc * PITCH + row] = hn[q] - ho[q];
-            Ht[cc * PITCH + row] = ho[q];
+            lds[0 * TILE + cc * PITCH + row] = h1[q] - h0[q];
+            lds[1 * TILE + cc * PITCH + row] = h0[q];
+            if constexpr (TWO) {
+                lds[2 * TILE + cc * PITCH + row] = h2[q] - h1[q];
+                lds[3 * TILE + cc * PITCH + row] = h1[q];
+            }
         }
         if (c0 + RESOLVE_COLS < col_hi) fetch(c0 + RESOLVE_COLS);
         __syncthreads();
 #pragma unroll
-        for (int p = 0; p < PER_WAVE; ++p) {
-            const int pair = wave + 4 * p;
-            if (pair < NPAIR) {                         // wave-uniform
-                const int bi = pair / NB, bj = pair % NB;
+        for (int m = 0; m < NM; ++m) {
+            if (m >= nm) continue;                      // (uniform)
+            const float* T = lds + m * TILE;
 #pragma unroll
-                for (int q = 0; q < RESOLVE_COLS / 4; ++q) {
-                    // fragment of block row bi: lane (m = c16, k = g4) = X[16 bi + m][column 4 q + k]; the
-                    // same layout serves as the B operand of X X^T with n = c16
-                    const int at = (4 * q + g4) * PITCH + c16;
-                    accD[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(Dt[at + 16 * bi], Dt[at + 16 * bj], accD[p], 0, 0, 0);
-                    accH[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ht[at + 16 * bi], Ht[at + 16 * bj], accH[p], 0, 0, 0);
+            for (int p = 0; p < PER_WAVE; ++p) {
+                const int pair = wave + 4 * p;
+                if (pair < NPAIR) {                     // wave-uniform
+                    const int bi = pair / NB, bj = pair % NB;
+#pragma unroll
+                    for (int q = 0; q < RESOLVE_COLS / 4; ++q) {
+                        // fragment of block row bi: lane (m = c16, k = g4) = X[16 bi + m][column 4 q + k]; the
+                        // same layout serves as the B operand of X X^T with n = c16
+                        const int at = (4 * q + g4) * PITCH + c16;
+                        acc[m][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(T[at + 16 * bi], T[at + 16 * bj], acc[m][p], 0, 0, 0);
+                    }
                 }
             }
         }
     }
     RESOLVE_MARK(2);
     // ---- 2. slab of this workgroup, then the last one adds them all ----
-    float* mine = slab + (size_t)blockIdx.x * 2 * RP * RP;
+    float* mine = slab + (size_t)blockIdx.x * NM * RP * RP;
 #pragma unroll
-    for (int p = 0; p < PER_WAVE; ++p) {
-        const int pair = wave + 4 * p;
-        if (pair < NPAIR) {
-            const int bi = pair / NB, bj = pair % NB;
+    for (int m = 0; m < NM; ++m) {
+        if (m >= nm) continue;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {               // acc[t] = S[16 bi + 4 g + t][16 bj + c]
-                const int at = (16 * bi + 4 * g4 + t) * RP + 16 * bj + c16;
-                __hip_atomic_store(mine + at, accD[p][t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(mine + RP * RP + at, accH[p][t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int p = 0; p < PER_WAVE; ++p) {
+            const int pair = wave + 4 * p;
+            if (pair < NPAIR) {
+                const int bi = pair / NB, bj = pair % NB;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {           // acc[t] = S[16 bi + 4 g + t][16 bj + c]
+                    const int at = (16 * bi + 4 * g4 + t) * RP + 16 * bj + c16;
+                    __hip_atomic_store(mine + m * RP * RP + at, acc[m][p][t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
         }
     }
@@ -921,13 +944,14 @@ __global__ __launch_bounds__(256) void screen_resolve_kernel(float* base, int r,
     __threadfence();
     RESOLVE_MARK(3);
     // (the staging tiles are dead: the double-precision matrices take their place)
-    double* S = reinterpret_cast<double*>(lds);         // [2][RP * RP]
+    double* S = reinterpret_cast<double*>(lds);         // [NM][RP * RP]
     // (the other workgroups released their slabs before they counted themselves in, and the fence above
     // is the acquire: ordinary vector loads from here on, many in flight)
     {
-        constexpr int QUADS = 2 * RP * RP / 4;
+        constexpr int QUADS = NM * RP * RP / 4;
+        const int quads = nm * RP * RP / 4;
         const float4* slab4 = reinterpret_cast<const float4*>(slab);
-        for (int e = tid; e < QUADS; e += 256) {
+        for (int e = tid; e < quads; e += 256) {
             double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
             unsigned w = 0;
             for (; w + 3 < gridDim.x; w += 4) {
@@ -947,9 +971,9 @@ __global__ __launch_bounds__(256) void screen_resolve_kernel(float* base, int r,
     }
     __syncthreads();
     RESOLVE_MARK(4);
-    // ---- 3. top eigenvalues: wave 0 of D D^T, wave 1 of H H^T ----
-    if (wave < 2) {
-        double* work = S + 2 * RP * RP + (size_t)wave * EIG_WORK;
+    // ---- 3. top eigenvalues: one wave per matrix ----
+    if (wave < nm) {
+        double* work = S + NM * RP * RP + (size_t)wave * EIG_WORK;
         int ok = 0;
         double* M = S + wave * RP * RP;
         const double theta = r <= 32 ? householder_top_wave(M, r, RP, work, lane, &ok)
@@ -965,9 +989,21 @@ __global__ __launch_bounds__(256) void screen_resolve_kernel(float* base, int r,
     const bool settled = ok_s[0] && ok_s[1] && lH > 0.0 && lD >= 0.0;     // else: left to the host
     const double dist = settled ? sqrt(lD) / sqrt(lH) : 0.0;
     const bool keep = dist > (double)tol;               // the loop test of src/onmf.py:252
-    if (settled && keep) {
-        // reopen the loop at sweep isel + 1 (the stopped launch had already run it once ahead of this verdict)
-        for (int j = isel + 1; j < SCREEN_MAX_SWEEPS && j < isel + 3; ++j) {
+    double lD1 = 0.0, lH1 = 0.0, dist1 = 0.0;
+    bool settled1 = false, keep1 = false;
+    if (two && settled && keep) {
+        lD1 = lam_s[2];
+        lH1 = lam_s[3];
+        settled1 = ok_s[2] && ok_s[3] && lH1 > 0.0 && lD1 >= 0.0;
+        dist1 = settled1 ? sqrt(lD1) / sqrt(lH1) : 0.0;
+        keep1 = dist1 > (double)tol;
+    }
+    // where the loop goes on: at sweep isel + 1 when only sweep isel was settled (the stopped launch had run
+    // that sweep once ahead of the verdict: it runs again), at isel + 2 when the sweep after it was too
+    // (its output is in the ring); nowhere after a stop
+    const int reopen = (settled && keep) ? (settled1 ? (keep1 ? isel + 2 : -1) : isel + 1) : -1;
+    if (reopen >= 0) {
+        for (int j = reopen; j < SCREEN_MAX_SWEEPS && j < reopen + 2; ++j) {
             for (int e = tid; e < ScreenLayout::SETSZ; e += 256) base[ScreenLayout::SETS + j * ScreenLayout::SETSZ + e] = 0.f;
             if (tid == 0) ibase[ScreenLayout::CNT + j] = 0;
         }
@@ -985,10 +1021,17 @@ __global__ __launch_bounds__(256) void screen_resolve_kernel(float* base, int r,
             rec[0] = (float)dist;
             rec[1] = (float)dist;
             rec[2] = keep ? 1.0f : 2.0f;
-            ibase[ScreenLayout::NRES] += 1;
-            if (keep) {
-                base[ScreenLayout::UBH + isel + 1] = (float)((sqrt(lH) + sqrt(lD)) * (1.0 + 1e-5));
-                ibase[ScreenLayout::NEXT] = isel + 1;
+            if (settled1) {
+                rec[4] = (float)dist1;
+                rec[5] = (float)dist1;
+                rec[6] = keep1 ? 1.0f : 2.0f;
+            }
+            ibase[ScreenLayout::NRES] += settled1 ? 2 : 1;
+            ibase[ScreenLayout::RNDS] += 1;
+            if (reopen >= 0) {
+                const double ub = reopen == isel + 2 ? sqrt(lH1) + sqrt(lD1) : sqrt(lH) + sqrt(lD);
+                base[ScreenLayout::UBH + reopen] = (float)(ub * (1.0 + 1e-5));
+                ibase[ScreenLayout::NEXT] = reopen;
                 __threadfence();
                 ibase[ScreenLayout::FLAG] = 0;
             } else {
@@ -1003,14 +1046,15 @@ __global__ __launch_bounds__(256) void screen_resolve_kernel(float* base, int r,
 template <int NB>
 int run_resolve(onmf_ctx* c, float* base, int r, int b, float* const* hb, int sub_iter, float tol, hipStream_t s) {
     constexpr int RP = 16 * NB;
+    constexpr int NM = NB <= 2 ? 4 : 2;
     // columns per workgroup: a multiple of the tile, at most 32 workgroups (the one that finishes last adds
     // up all their slabs)
     int cols = std::max(RESOLVE_COLS, (b + 31) / 32);
     cols = (cols + RESOLVE_COLS - 1) / RESOLVE_COLS * RESOLVE_COLS;
     const int nwg = (b + cols - 1) / cols;
-    ONMF_TRY(onmf_reserve(c, c->rslab, (size_t)nwg * 2 * RP * RP * sizeof(float), "verdict resolution slabs"));
-    const size_t tiles = (size_t)2 * RESOLVE_COLS * (RP + 4) * sizeof(float);
-    const size_t mats = ((size_t)2 * RP * RP + 2 * eig_work_doubles(RP)) * sizeof(double);
+    ONMF_TRY(onmf_reserve(c, c->rslab, (size_t)nwg * NM * RP * RP * sizeof(float), "verdict resolution slabs"));
+    const size_t tiles = (size_t)NM * RESOLVE_COLS * (RP + 4) * sizeof(float);
+    const size_t mats = ((size_t)NM * RP * RP + NM * eig_work_doubles(RP)) * sizeof(double);
     const size_t lds = std::max(tiles, mats);
     static LdsLimit lim;
     ONMF_TRY(onmf_raise_lds_limit(c, lim, (const void*)screen_resolve_kernel<NB>, lds));

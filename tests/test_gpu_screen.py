@@ -365,3 +365,46 @@ def test_tests_acted_on_three_sweeps_later_change_nothing(eng, d, r, b):
                 eng.set_option(LAG3, 1)
             assert s == se, (tol, lag3, s, se)
             assert torch.equal(H, He), (tol, lag3)
+
+
+@pytest.mark.parametrize("d,r,b,tol", [(441, 25, 1000, 0.01), (100, 16, 700, 0.02), (150, 32, 2000, 0.02)])
+def test_early_stopping_streams_settle_their_tests_on_the_device_by_default(eng, d, r, b, tol):
+    """Default options, r <= 32, a stream whose solves stop early: after the first solve that needed a full
+    evaluation the following ones carry device rounds, each of which settles the inconclusive sweep and the
+    one after it.  The chain - waited for, and not waited for (ONMF_OPT_DEFER_VERDICT) - must run the sweep
+    counts of the chain that evaluates every test in full on the host and leave the same state bit for bit;
+    and the device must indeed have settled tests."""
+    import torch
+    g = torch.Generator(device=eng.device).manual_seed(13 * d + r)
+    Xs = [torch.rand(d, b, device=eng.device, generator=g) for _ in range(8)]
+    W0 = torch.rand(d, r, device=eng.device, generator=g)
+    eng.set_option(EXACT, 1)             # (tolerances that these streams reach after 3 to 8 sweeps)
+
+    def chain(defer):
+        A, B, W = eng.zeros(r, r), eng.zeros(r, d), W0.clone()
+        c0 = eng.counters()
+        sweeps = []
+        for t, X in enumerate(Xs):
+            H, A, B, _, W, s, _ = eng.step(X, A, B, None, W, 1.0 / (t + 1), seed=2000 + t, stopping_diff=tol, defer=defer)
+            sweeps.append(s)
+        eng.settle()
+        torch.cuda.synchronize()
+        c1 = eng.counters()
+        return (H.clone(), A.clone(), B.clone(), W.clone(), c1["sweeps_total"] - c0["sweeps_total"],
+                c1["device_resolves"] - c0["device_resolves"], sweeps)
+
+    He, Ae, Be, We, ne, _, swe = chain(False)
+    eng.set_option(EXACT, 0)
+    assert ne == sum(swe) and sum(s < 10 for s in swe) >= 5, swe          # most of the stream's solves stop early
+    Hw, Aw, Bw, Ww, nw, resolved_w, sww = chain(False)
+    eng.set_option(DEFER, 1)
+    try:
+        Hd, Ad, Bd, Wd, nd, resolved_d, _ = chain(True)
+    finally:
+        eng.set_option(DEFER, 0)
+    print("d=%d r=%d b=%d tol=%.4g: sweeps %s, tests settled on the device: %d waited, %d not waited" % (
+        d, r, b, tol, swe, resolved_w, resolved_d))
+    assert sww == swe and nw == ne == nd
+    for got in ((Hw, Aw, Bw, Ww), (Hd, Ad, Bd, Wd)):
+        assert all(torch.equal(x, y) for x, y in zip(got, (He, Ae, Be, We)))
+    assert resolved_w > 0 and resolved_d > 0
