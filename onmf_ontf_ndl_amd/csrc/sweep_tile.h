@@ -195,11 +195,12 @@ __global__ __launch_bounds__(64 * WPG + (sweep_has_control_wave<NB, HALF, PROBE,
                 }
                 return screen_eval_wave(sc.base, j, ubc, sc.tol, sc.rank_cap, blockIdx.x == 0, -1.0f, cw);
             };
-            auto post_sums = [&](int j) {                  // this workgroup's sums of sweep j, then its count
+            // this workgroup's sums of sweep j go out (post_issue), then its count (post_finish)
+            auto post_issue = [&](int j, float& back_f, double& back_d) {
                 float* cur = sc.base + ScreenLayout::SETS + j * ScreenLayout::SETSZ;
                 const int rep = blockIdx.x % SCREEN_REPL;
-                float back_f = 0.f;
-                double back_d = 0.0;
+                back_f = 0.f;
+                back_d = 0.0;
                 if (lane < 16) {
                     back_f = atomicAdd(&cur[ScreenLayout::SET_P2 + rep * 16 + lane], p2_of(j & 1)[lane]);
                 } else if (lane < 18) {
@@ -212,12 +213,20 @@ __global__ __launch_bounds__(64 * WPG + (sweep_has_control_wave<NB, HALF, PROBE,
                         back_d += atomicAdd(reinterpret_cast<double*>(cur + ScreenLayout::SET_Y) + yrep * SCREEN_CW_ROWS + q,
                                             (double)y_of(j & 1)[q]);
                 }
-                // (they return, and the count goes out only after every one of them has: whoever sees the
+            };
+            auto post_finish = [&](int j, float back_f, double back_d) {
+                // (the atomics return, and the count goes out only after every one of them has: whoever sees the
                 // count complete finds all sums in place, without any cache maintenance)
                 asm volatile("s_waitcnt vmcnt(0)" ::"v"(back_f), "v"(back_d) : "memory");
                 if (lane == 0)
                     __hip_atomic_fetch_add(reinterpret_cast<int*>(sc.base) + ScreenLayout::CNT + j, 1, __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_AGENT);
+            };
+            auto post_sums = [&](int j) {
+                float back_f;
+                double back_d;
+                post_issue(j, back_f, back_d);
+                post_finish(j, back_f, back_d);
             };
             // the verdict the first sweep of the launch starts with (its sums were all posted before the launch)
             // sc.lag = 2: the test of sweep k - 1 is evaluated during sweep k, behind this workgroup's own sums
@@ -236,9 +245,20 @@ __global__ __launch_bounds__(64 * WPG + (sweep_has_control_wave<NB, HALF, PROBE,
             for (int k = k_first; k < k_first + k_count; ++k) {
                 __syncthreads();                           // the tile waves enter the block loop of sweep k
                 verdict = 0;
-                if (k - 1 >= k_first) post_sums(k - 1);
                 const int j = k + 1 - lag;
-                if (j >= v_first) verdict = test_of(j);
+                if (lag == 3) {
+                    // the tested sweep's sums do not include the ones going out now: its loads travel with
+                    // these atomics (one round trip to memory instead of two in a row)
+                    float back_f = 0.f;
+                    double back_d = 0.0;
+                    const bool posting = k - 1 >= k_first;
+                    if (posting) post_issue(k - 1, back_f, back_d);
+                    if (j >= v_first) verdict = test_of(j);
+                    if (posting) post_finish(k - 1, back_f, back_d);
+                } else {
+                    if (k - 1 >= k_first) post_sums(k - 1);
+                    if (j >= v_first) verdict = test_of(j);
+                }
                 if (lane == 0) *verdict_of((k + 1) & 1) = verdict;
                 __syncthreads();                           // the tile waves' sums of sweep k are in LDS
                 if (verdict != 0) return;                  // (the tile waves leave at the top of sweep k + 1)

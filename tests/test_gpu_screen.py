@@ -208,7 +208,7 @@ def test_inconclusive_verdicts_are_settled_on_the_device_for_small_r(eng, d, r, 
     _, _, de = eng.sparse_code(X, W, H0=H0, sub_iter=12, stopping_diff=0.0)
     eng.set_option(EXACT, 0)
     assert len(de) == 12
-    eng.set_option(9, 1)                          # device-side resolution is opt-in
+    eng.set_option(9, 1)                          # device rounds behind every solve that needed a full evaluation
     for k in (3, 6, 9):
         for tol in (float(min(de[:k + 1]) * 0.995), float(de[k] * 1.005)):
             eng.set_option(EXACT, 1)
@@ -225,7 +225,7 @@ def test_inconclusive_verdicts_are_settled_on_the_device_for_small_r(eng, d, r, 
             if se - 1 < len(de):
                 np.testing.assert_allclose(third[2][se - 1], de[se - 1], rtol=1e-4)
             assert eng.counters()["device_resolves"] >= before + 1, (k, tol)
-    # switched off (the default): same results, nothing settled on the device
+    # switched off: same results, nothing settled on the device
     eng.set_option(9, 0)
     try:
         before = eng.counters()["device_resolves"]
@@ -238,7 +238,7 @@ def test_inconclusive_verdicts_are_settled_on_the_device_for_small_r(eng, d, r, 
             assert ss == se and torch.equal(Hs, He)
         assert eng.counters()["device_resolves"] == before
     finally:
-        eng.set_option(9, 0)
+        eng.set_option(9, -1)                     # (the default)
 
 
 @pytest.mark.parametrize("d,r,b", [(300, 64, 4096), (120, 25, 1000), (200, 128, 2048)])
@@ -378,6 +378,7 @@ def test_early_stopping_streams_settle_their_tests_on_the_device_by_default(eng,
     g = torch.Generator(device=eng.device).manual_seed(13 * d + r)
     Xs = [torch.rand(d, b, device=eng.device, generator=g) for _ in range(8)]
     W0 = torch.rand(d, r, device=eng.device, generator=g)
+    eng.set_option(9, -1)                # (the default, whatever an earlier test left)
     eng.set_option(EXACT, 1)             # (tolerances that these streams reach after 3 to 8 sweeps)
 
     def chain(defer):

@@ -28,6 +28,7 @@ names = ["start barrier", "block loop", "partial sums", "barrier", "atomics out,
          "test ahead", "atomics back", "barrier"]
 ORDER = [0, 1, 2, 3, 4, 8, 5, 6, 7]          # mark 8 sits between 4 and 5
 acc = np.zeros(8)
+ctrl = False
 per_sweep = []
 n = 0
 for rep in range(8):
@@ -38,10 +39,17 @@ for rep in range(8):
     if rep < 2:
         continue
     for k in range(2, 9):
-        acc += np.diff(m[k][ORDER]) * 0.01
+        if m[k][5] == 0:          # a kernel with a control wave: the tile waves' sweep ends at the barrier (mark 4)
+            ctrl = True
+            acc[:4] += np.diff(m[k][[0, 1, 2, 3, 4]]) * 0.01
+            acc[4:] = 0
+        else:
+            acc += np.diff(m[k][ORDER]) * 0.01
         per_sweep.append((m[k + 1][0] - m[k][0]) * 0.01)
         n += 1
 print("d=%d r=%d b=%d: %.2f us per sweep (workgroup 0, sweeps 2..8 of 10)" % (d, r, b, np.mean(per_sweep)))
-for nm, v in zip(names, acc / n):
+if ctrl:
+    print("  (control-wave kernel: the tile waves' sweep ends at the barrier behind the partial sums)")
+for nm, v in zip(names[:4] if ctrl else names, acc / n):
     print("  %-42s %6.2f us" % (nm, v))
 print("  %-42s %6.2f us" % ("to the next sweep's start", np.mean(per_sweep) - acc.sum() / n))
