@@ -460,10 +460,10 @@ __global__ __launch_bounds__(256) void screen_cw_finish_kernel(int r, float* bas
 // stopped had run sweep i + 1 ahead of the verdict, so its move is in the ring of three buffers too, and the
 // two waves that would idle through step 3 take its two matrices; the loop then goes on at sweep i + 2.
 // Measured (MI355X, d=441 r=25 b=1000, where every solve stops early and three of its tests - the stop and the
-// two sweeps before it, 2 to 15 % above the threshold - need a full evaluation): the kernel takes 47 us, of
-// which 38 are step 3 (tridiagonalisation 32, multisection 6: a lone wave issues an instruction every seven or
-// eight clocks, and the algorithm is a chain of 23 dependent reflections), against about 60 us per test with
-// the host in the loop.  Two rounds of (verdict kernel, this kernel, sweep launch) per solve: a step takes
+// two sweeps before it, 2 to 15 % above the threshold - need a full evaluation): the kernel takes 50 us, of
+// which 30 or so are step 3 (tridiagonalisation 24, multisection 6: a lone wave issues an instruction every
+// seven or eight clocks, and the algorithm is a chain of 23 dependent reflections), against about 60 us per
+// test with the host in the loop.  Two rounds of (verdict kernel, this kernel, sweep launch) per solve: a step takes
 // 0.23 ms against 0.30 with the host (0.315 with one sweep per round, i.e. three rounds).  At r = 64 (Lanczos,
 // one sweep per round) a round costs about what the host's evaluation does.  Hence the default of
 // ONMF_OPT_DEVICE_RESOLVE (api.hip).  (A power iteration in step 3 was far worse at small r: the moves' Gram
@@ -717,89 +717,67 @@ __device__ double lanczos_top_wave(const double* M, int n, int RP, double* work,
     return tridiag_top_wave(al, be, m, prev > 0.0 ? prev : ninf, lane, coef);
 }
 
-// The same value for small matrices (n <= 32) by Householder tridiagonalisation, one wave: n - 2 reflections,
-// each a product with the trailing matrix, two wave-wide sums and a symmetric rank-two update - exact after a
-// fixed number of operations whatever the spectrum, and a fraction of what the Lanczos run with its
-// re-orthogonalisation costs at these sizes.  Lane j works on column j of the matrix, which stays in LDS (M: n x n
-// doubles, rows RP apart, overwritten); the entries of the reflector and of the update's vector are broadcast
-// from LDS.  A lone wave issues an instruction every seven or eight clocks and fetches straight-line code
-// slower than it runs it (a version unrolled over the reflections, matrix in registers, took longer for its
-// instruction fetches than this one for its LDS round trips), so: short loops, few instructions.
-// work: the multisection's coefficient pairs, 64 doubles, 64 pairs of doubles (16-byte aligned).
-__device__ double householder_top_wave(double* M, int n, int RP, double* work, int lane, int* ok) {
-    double* coef = work;
-    double* xs = work + TRIDIAG_COEF_DOUBLES;
-    double2* uq = reinterpret_cast<double2*>(xs + 64);
+// The same value for small matrices (n <= N, N = 16 or 32) by Householder tridiagonalisation, one wave: n - 2
+// reflections, each a product with the trailing matrix, two wave-wide sums and a symmetric rank-two update -
+// exact after a fixed number of operations whatever the spectrum, and a fraction of what the Lanczos run with
+// its re-orthogonalisation costs at these sizes.  Lane j keeps column j of the matrix in registers (rows and
+// columns from n on are zero); entries of the reflector and of the update's vector travel by v_readlane, so
+// the loops touch no memory - at the price of straight-line code, unrolled over the reflections, that a lone
+// wave fetches about as slowly as it runs it (24 us at n = 25 against 32 us for the same steps with the matrix
+// in LDS and rolled loops, whose every batch of rows waits for an LDS round trip).
+// M: n x n doubles in LDS, rows RP apart (read once).  work: the multisection's coefficient pairs.
+template <int N>
+__device__ double householder_top_wave(const double* M, int n, int RP, double* work, int lane, int* ok) {
     *ok = 1;
+    double m[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) m[i] = (lane < n && i < n) ? M[i * RP + lane] : 0.0;
     double f = 0.0;
-    if (lane < n) {
-#pragma unroll 4
-        for (int j = 0; j < n; ++j) f = fma(M[j * RP + lane], M[j * RP + lane], f);
-    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) f = fma(m[i], m[i], f);
     const double fro = wave_add_f64(f);
     if (!(fro > 0.0)) {
         *ok = (fro == 0.0);
         return 0.0;
     }
-    if (n == 1) return M[0];
+    if (n == 1) return lane_f64(m[0], 0);
     double a_mine = 0.0, b_mine = 0.0;                              // lane k: a_k and b_k of the tridiagonal
-    double* col = M + lane;                                         // column `lane` = row `lane` (symmetric)
-    for (int k = 0; k + 1 < n; ++k) {
-        const bool act = lane > k && lane < n;
-        const double mk = lane < n ? col[k * RP] : 0.0;
-        if (lane == k) a_mine = mk;
-        const double x = act ? mk : 0.0;
-        double bk;
+#pragma unroll
+    for (int k = 0; k + 1 < N; ++k) {
+        if (k + 1 >= n) continue;                                   // (wave-uniform)
+        if (lane == k) a_mine = m[k];
+        const double x = lane > k ? m[k] : 0.0;                     // row k = column k (symmetric)
+        const double x0 = lane_f64(x, k + 1);
+        double bk = x0;
         if (k + 2 < n) {
-            xs[lane] = x;
-            wave_lds_fence();
-            const double x0 = xs[k + 1];
-            bk = x0;
             // y = S x over the trailing rows, before the reflector's scale is known: S u = S x - alpha S e_{k+1}
             // and u^T S u = x^T S x - 2 alpha (S x)_{k+1} + alpha^2 S_{k+1,k+1}, so both sums of the step (|x|^2
-            // and x^T S x) travel through the wave together
-            double y0 = 0.0, y1 = 0.0, mk1 = 0.0;
-            if (act) {
-                mk1 = col[(k + 1) * RP];
-                y0 = mk1 * x0;
-                int i = k + 2;
-                for (; i + 1 < n; i += 2) {
-                    y1 = fma(col[i * RP], xs[i], y1);
-                    y0 = fma(col[(i + 1) * RP], xs[i + 1], y0);
-                }
-                if (i < n) y1 = fma(col[i * RP], xs[i], y1);
-            }
-            const double y = y0 + y1;
+            // and x^T S x) travel through the wave together, and the square root waits for one reduction only
+            double y4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int i = k + 1; i < N; ++i)
+                if ((i & ~3) < n) y4[i & 3] = fma(m[i], lane_f64(x, i), y4[i & 3]);      // (rows from n on are zero)
+            const double y = (y4[0] + y4[1]) + (y4[2] + y4[3]);
             double nx2 = x * x, xy = x * y;
             wave_add2_f64(nx2, xy);
             if (nx2 > x0 * x0) {                                    // something below the sub-diagonal: reflect
                 const double nx = nx2 * rsqrt_newton_f64(nx2);
                 const double alpha = x0 > 0.0 ? -nx : nx;
                 const double tau = rcp_newton_f64(fma(nx, fabs(x0), nx2));     // 2 / |u|^2,  u = x - alpha e_{k+1}
-                const double usu = fma(alpha * alpha, lane_f64(mk1, k + 1), fma(-2.0 * alpha, lane_f64(y, k + 1), xy));
+                const double usu = fma(alpha * alpha, lane_f64(m[k + 1], k + 1), fma(-2.0 * alpha, lane_f64(y, k + 1), xy));
                 const double u = (lane == k + 1) ? x - alpha : x;
-                const double pj = tau * fma(-alpha, mk1, y);        // tau S u  (lane j: S_{j,k+1} = S_{k+1,j})
+                const double pj = tau * fma(-alpha, m[k + 1], y);   // tau S u  (lane j: S_{j,k+1} = S_{k+1,j} = m[k+1])
                 const double q = fma(-0.5 * tau * tau * usu, u, pj);
-                uq[lane] = make_double2(-u, -q);
-                wave_lds_fence();
-                if (act) {
-#pragma unroll 4
-                    for (int i = k + 1; i < n; ++i) {
-                        const double2 c = uq[i];
-                        col[i * RP] = fma(c.x, q, fma(c.y, u, col[i * RP]));
-                    }
-                }
-                wave_lds_fence();
+#pragma unroll
+                for (int i = k + 1; i < N; ++i)
+                    if ((i & ~3) < n) m[i] = fma(-lane_f64(u, i), q, fma(-lane_f64(q, i), u, m[i]));
                 bk = alpha;
             }
-        } else {
-            bk = lane_f64(x, k + 1);
-            const double last = lane_f64(lane < n ? col[(k + 1) * RP] : 0.0, k + 1);
-            if (lane == k + 1) a_mine = last;
         }
         if (lane == k) b_mine = bk;
+        if (k + 2 == n && lane == k + 1) a_mine = m[k + 1];
     }
-    return tridiag_top_lanes(a_mine, b_mine, n, -__builtin_inf(), lane, coef);
+    return tridiag_top_lanes(a_mine, b_mine, n, -__builtin_inf(), lane, work);
 }
 
 // work space of one wave's eigenvalue run, in doubles (even: its (u, q) pairs are read 16 bytes at a time)
@@ -976,8 +954,10 @@ __global__ __launch_bounds__(256) void screen_resolve_kernel(float* base, int r,
         double* work = S + NM * RP * RP + (size_t)wave * EIG_WORK;
         int ok = 0;
         double* M = S + wave * RP * RP;
-        const double theta = r <= 32 ? householder_top_wave(M, r, RP, work, lane, &ok)
-                                     : lanczos_top_wave(M, r, RP, work, lane, &ok);
+        double theta;
+        if constexpr (RP <= 16) theta = householder_top_wave<16>(M, r, RP, work, lane, &ok);
+        else if constexpr (RP <= 32) theta = householder_top_wave<32>(M, r, RP, work, lane, &ok);
+        else theta = lanczos_top_wave(M, r, RP, work, lane, &ok);
         if (lane == 0) {
             lam_s[wave] = theta;
             ok_s[wave] = ok;
