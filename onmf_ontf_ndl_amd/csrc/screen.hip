@@ -932,6 +932,15 @@ __global__ __launch_bounds__(256) void screen_resolve_kernel(float* base, int r,
         for (int e = tid; e < quads; e += 256) {
             double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
             unsigned w = 0;
+            for (; w + 7 < gridDim.x; w += 8) {             // (eight slabs' loads in flight: one round trip)
+                float4 v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = slab4[(size_t)(w + j) * QUADS + e];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    s0 += (double)v[j].x; s1 += (double)v[j].y; s2 += (double)v[j].z; s3 += (double)v[j].w;
+                }
+            }
             for (; w + 3 < gridDim.x; w += 4) {
                 const float4 a = slab4[(size_t)(w + 0) * QUADS + e], bq = slab4[(size_t)(w + 1) * QUADS + e];
                 const float4 cq = slab4[(size_t)(w + 2) * QUADS + e], dq = slab4[(size_t)(w + 3) * QUADS + e];
