@@ -668,10 +668,13 @@ int launch_gemm_pair(onmf_ctx* c, bool a_km, bool b_kn, int M, int K, const floa
     const int tiles_m = (M + bm - 1) / bm, tiles_n = (N + BN - 1) / BN;
     const int tiles = tiles_m * tiles_n;
     const int ktiles = (K + BK - 1) / BK;
-    int splits = (tiles > 4 && tiles < 256 && ktiles >= 4) ? std::min(SPLIT_WG_BUDGET / tiles, ktiles / 2) : 1;
+    // (a handful of tiles: one workgroup per CU, as for a single product of that size)
+    int splits = (tiles < 256 && ktiles >= 4) ? std::min((tiles <= 4 ? 256 + tiles - 1 : SPLIT_WG_BUDGET) / tiles, ktiles / 2)
+                                              : 1;
     // (padding of more than half a tile per row of tiles of the first product is not worth the launch saved
-    // when that product is most of the work)
-    const bool pad_ok = N1p == N1 || (N1p - N1) * 4 <= N;
+    // when that product is most of the work - unless the pair is a handful of tiles, where a launch and its
+    // reduction cost more than any padding)
+    const bool pad_ok = N1p == N1 || (N1p - N1) * 4 <= N || tiles <= 4;
     if (!pad_ok || splits < 2 || (beta1 != 0.f && !Cin1) || (beta2 != 0.f && !Cin2)) {
         ONMF_TRY(launch_gemm(c, a_km, b_kn, M, N1, K, A, lda, B1, ldb1, alpha, beta1, Cin1, C1, ldc1, s, slab));
         return launch_gemm(c, a_km, b_kn, M, N2, K, A, lda, B2, ldb2, alpha, beta2, Cin2, C2, ldc2, s, slab);
