@@ -284,9 +284,7 @@ __global__ __launch_bounds__(256) void dict_panel_kernel(int d, int r, int lda,
                                                          const float* __restrict__ Wt,
                                                          float* __restrict__ WtOut, float* Dt, int nwg,
                                                          u64* granules, int* timeout_flag, long long spin_limit,
-                                                         int j_begin, int j_end, float* __restrict__ Wdirect) {
-    // Wdirect (small passes): the new atoms go straight into W (d x r, row-major) instead of W^T - strided
-    // stores, which a pass of a few thousand entries does not feel, and no transposing launch behind it.
+                                                         int j_begin, int j_end) {
     // atoms j_begin .. j_end-1 (multiples of the panel width): a later launch goes on where an earlier
     // one stopped - all it needs of the earlier atoms are their deltas in Dt (the left-looking update
     // reads them from memory anyway)
@@ -318,14 +316,7 @@ __global__ __launch_bounds__(256) void dict_panel_kernel(int d, int r, int lda,
     const auto rs_o = __builtin_amdgcn_make_buffer_rsrc((void*)WtOut, 0, nbytes, 0x00020000);
     const auto rs_d = __builtin_amdgcn_make_buffer_rsrc((void*)Dt, 0, nbytes, 0x00020000);
     const auto rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)Ap, 0, (unsigned)r * (unsigned)lda * 4u, 0x00020000);
-    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(Wdirect ? Wdirect : WtOut), 0, nbytes, 0x00020000);
     const int rowbytes = d * 4;
-    int voffW[RPT];           // Wdirect: byte offset of the thread's rows in W
-#pragma unroll
-    for (int p = 0; p < RPT; ++p) {
-        const int i = row0 + p * 256 + tid;
-        voffW[p] = i < d ? i * r * 4 : (int)0x80000000;
-    }
     int voff[RPT];            // the thread's own rows: p * 256 + tid
     int voffB[RPT][4];        // MFMA B operand: row p * 256 + wave * 64 + 16 mt + c16, atom offset g4
 #pragma unroll
@@ -500,11 +491,7 @@ __global__ __launch_bounds__(256) void dict_panel_kernel(int d, int r, int lda,
             for (int p = 0; p < RPT; ++p) {
                 const float wn = u[p] * scale;
                 const float dv = wn - w[p][n];
-                if (Wdirect != nullptr) {                     // (uniform; padded atoms have no column in W)
-                    if (j < r) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(wn), rs_x, voffW[p], j * 4, 0);
-                } else {
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(wn), rs_o, voff[p], j * rowbytes, 0);
-                }
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(wn), rs_o, voff[p], j * rowbytes, 0);
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dv), rs_d, voff[p], j * rowbytes, 0);
 #pragma unroll
                 for (int m = 0; m < PW; ++m)             // (constant bounds: unrolls before n is known)
@@ -733,8 +720,6 @@ int launch_dict_pass(onmf_ctx* c, int d, int r, const float* Win, const float* A
                                dim3(256), head_lds, s, d, r, lda, A, Win, B, Qt, Wt, Ap);
             HIP_TRY(c, hipGetLastError());
         }
-        // a whole pass of a few thousand entries in one workgroup: the new atoms go straight into W
-        const bool direct = nwg == 1 && part == 0 && (size_t)d * r <= 16384;
         // 256 threads, thread t owns rows t, t + 256, ... of its workgroup's 1024
         const int rpt = nwg > 1 ? 4 : (d + 255) / 256;
         const int nt = rpt > 1 ? 256 : (d + 63) / 64 * 64;
@@ -744,13 +729,13 @@ int launch_dict_pass(onmf_ctx* c, int d, int r, const float* Win, const float* A
         // waiting for the pass to end.)
 #define PANEL_CASE(RPTV)                                                                              \
     hipLaunchKernelGGL((dict_panel_kernel<RPTV>), dim3(nwg), dim3(nt), 0, s, d, r, lda, Qt, Ap, Wt, WtOut, Dt, \
-                       nwg, gran, flag, spin_limit, j_begin, j_end, direct ? Wout : nullptr);
+                       nwg, gran, flag, spin_limit, j_begin, j_end);
         if (rpt <= 1) PANEL_CASE(1)
         else if (rpt <= 2) PANEL_CASE(2)
         else PANEL_CASE(4)
 #undef PANEL_CASE
         HIP_TRY(c, hipGetLastError());
-        if (part == 1 || direct) return ONMF_OK;
+        if (part == 1) return ONMF_OK;
         ONMF_TRY(launch_transpose(r, d, WtOut, Wout, s));
         if (nwg > 1) {
             // what to do if a workgroup gave up waiting: decided and done on the device (one near-empty
